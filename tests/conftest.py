@@ -1,0 +1,34 @@
+"""pytest config: registers the ``gpu`` marker and puts the product package dir on sys.path.
+
+``-m "not gpu"`` runs here on CPU (oracle vs golden fixtures, host logic, C-ABI symbol
+check, gloo world_size-2 sharding); ``-m gpu`` runs on one MI355X and calls the HIP path
+through the C-ABI, checked against the oracle and the committed fixtures.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "msra-practice-project_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP path through the C-ABI)")
+
+
+def load_golden(name):
+    """Load a committed fixture (plain arrays only; allow_pickle stays False)."""
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as f:
+        return {k: f[k] for k in f.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

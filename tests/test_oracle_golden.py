@@ -1,0 +1,158 @@
+"""CPU: the oracle restatement reproduces every golden fixture taken from the reference.
+
+The fixtures were produced by tests/golden/make_golden.py importing the reference on
+CPU fp32 (the reference has no tests of its own: SURVEY.md §4).  Same torch build ->
+the restatement is expected to match bit for bit; the asserts allow 1e-6 so a different
+BLAS threading split cannot flake them.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields, render_ref as R, synth
+
+TOL = 1e-6
+
+
+def close(a, b, tol=TOL):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().numpy()
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= tol, err
+
+
+def test_f1_rays_and_poses(golden):
+    g = golden("rays_f1")
+    W, H = int(g["W"]), int(g["H"])
+    pose_n = synth.pose_degrees(4.0, 37.0, -30.0)
+    pose_p = synth.pose_radians(1.0, 0.2, -0.15)
+    assert np.array_equal(pose_n, g["pose_nerf"]) and pose_n.dtype == np.float32
+    assert np.array_equal(pose_p, g["pose_pigan"])
+    o, d = R.get_rays(W, H, float(g["focal"]), pose_n)
+    assert d.dtype == np.float32
+    assert np.array_equal(o, g["rays_o"]) and np.array_equal(d, g["rays_d"])
+    o, d = R.get_rays(W, H, float(g["focal_pigan"]), pose_p)
+    assert np.array_equal(o, g["rays_o_pigan"]) and np.array_equal(d, g["rays_d_pigan"])
+
+
+@pytest.mark.parametrize("name", ["composite_f2", "composite_f2_s36", "composite_f2_s192"])
+def test_f2_composite(golden, name):
+    g = golden(name)
+    rgb, depth, acc, w = R.composite(*(torch.from_numpy(g[k]) for k in ("raw", "z", "rays_d")))
+    for got, key in ((rgb, "rgb"), (depth, "depth"), (acc, "acc"), (w, "weights")):
+        close(got, g[key])
+
+
+def test_f3_sample_pdf(golden):
+    g = golden("pdf_f3")
+    bins, w = torch.from_numpy(g["bins"]), torch.from_numpy(g["weights"])
+    for nf in (0, 1, 24, 128):
+        got = R.sample_pdf(bins, w, nf)
+        assert tuple(got.shape) == (bins.shape[0], nf)
+        close(got, g[f"samples_{nf}"])
+    close(R.sample_pdf(torch.from_numpy(g["bins11"]), torch.from_numpy(g["weights11"]), 24), g["samples11_24"])
+
+
+@pytest.mark.parametrize("kind", ["nerf", "siren_nerf", "film_siren_nerf", "film_siren_nerf_nodir"])
+@pytest.mark.parametrize("sharp", [False, True])
+def test_f4_fields(golden, kind, sharp):
+    g = golden("field_f4")
+    tag = f"{kind}{'_sharp' if sharp else ''}"
+    sd = synth.state_dict(kind, seed=10, sharp=sharp, bias_jitter=0.05)
+    assert synth.digest(sd) == str(g[f"digest.{tag}"]), "synthetic weights drifted from the fixture's"
+    film = torch.from_numpy(g["film"])[1] if kind.startswith("film") else None
+    with torch.no_grad():
+        out = fields.make_field(kind, sd, film)(torch.from_numpy(g["x"]))
+    close(out, g[f"out.{tag}"], 2e-6)
+
+
+def test_macs_match_survey():
+    assert fields.MACS["nerf"] == 591488
+    assert fields.MACS["siren_nerf"] == 559616
+    assert fields.MACS["film_siren_nerf"] == 526848
+    assert sum(np.prod(s) for s in fields.param_shapes("nerf").values()) == 593924
+
+
+F5 = [
+    ("render_f5_nerf_32_0_sharp", "nerf", 32, 0, True),
+    ("render_f5_nerf_64_0_sharp", "nerf", 64, 0, True),
+    ("render_f5_nerf_64_128_sharp", "nerf", 64, 128, True),
+    ("render_f5_nerf_64_128", "nerf", 64, 128, False),
+    ("render_f5_siren_nerf_64_128", "siren_nerf", 64, 128, False),
+]
+
+
+@pytest.mark.parametrize("name,kind,nc,nf,sharp", F5)
+def test_f5_render_rays(golden, name, kind, nc, nf, sharp):
+    g = golden(name)
+    sd_c = synth.state_dict(kind, seed=20, sharp=sharp, bias_jitter=0.05)
+    sd_f = synth.state_dict(kind, seed=21, sharp=sharp, bias_jitter=0.05)
+    assert synth.digest(sd_c) == str(g["digest_c"]) and synth.digest(sd_f) == str(g["digest_f"])
+    with torch.no_grad():
+        tr = R.render_rays(torch.from_numpy(g["rays"]), float(g["near"]), float(g["far"]),
+                           fields.make_field(kind, sd_c), fields.make_field(kind, sd_f), nc, nf,
+                           torch.from_numpy(g["t_rand"]))
+    for key in tr._fields:
+        close(getattr(tr, key), g[key], 2e-6)
+
+
+@pytest.mark.parametrize("kind", ["film_siren_nerf", "film_siren_nerf_nodir"])
+def test_f5_render_rays_pigan(golden, kind):
+    g = golden(f"render_f5_{kind}_12_24")
+    sd = synth.state_dict(kind, seed=30, sharp=True)
+    assert synth.digest(sd) == str(g["digest"])
+    f = fields.make_field(kind, sd, torch.from_numpy(g["film"]))
+    with torch.no_grad():
+        tr = R.render_rays(torch.from_numpy(g["rays"]), 0.5, 1.5, f, f, 12, 24, torch.from_numpy(g["t_rand"]))
+    for key in tr._fields:
+        close(getattr(tr, key), g[key], 2e-6)
+
+
+def _check_grads(g, prefix, named):
+    for name, p in named:
+        gr = p.grad.detach().numpy().reshape(-1)
+        key = f"g.{prefix}{name}"
+        ref = g[key + ".val"]
+        scale = max(float(g[key + ".l2"]), 1e-12)
+        assert np.abs(gr[g[key + ".idx"]] - ref).max() <= 1e-5 * scale + 1e-7, name
+        assert abs(np.sqrt((gr.astype(np.float64) ** 2).sum()) - float(g[key + ".l2"])) <= 1e-5 * scale + 1e-9
+
+
+def test_f6_pigan_image_and_grads(golden):
+    g = golden("pigan_grad_f6")
+    res, nc, nf = int(g["res"]), int(g["n_coarse"]), int(g["n_fine"])
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.state_dict("film_siren_nerf", seed=40, sharp=True).items()}
+    film = torch.from_numpy(g["film"]).clone().requires_grad_(True)
+    focal = res / 2 / np.tan(float(g["fov"]) / 2 * np.pi / 180)
+    imgs = []
+    for i in range(film.shape[0]):
+        pose = synth.pose_radians(1, float(g["thetas"][i]), float(g["phis"][i]))
+        rays = torch.from_numpy(R.rays_from_camera(res, res, focal, pose))
+        f = fields.make_field("film_siren_nerf", sd, film[i])
+        tr = R.render_rays(rays, float(g["near"]), float(g["far"]), f, f, nc, nf, torch.from_numpy(g["t_rand"][i]))
+        imgs.append(tr.rgb_f.reshape(res, res, 3))
+    img = torch.stack(imgs)
+    close(img, g["image"], 2e-6)
+    (img * torch.from_numpy(g["cotangent"])).sum().backward()
+    scale = float(np.abs(g["grad_film"]).max())
+    assert np.abs(film.grad.numpy() - g["grad_film"]).max() <= 1e-4 * scale
+    _check_grads(g, "", [(k, v) for k, v in sd.items()])
+
+
+def test_f7_nerf_loss_grads(golden):
+    g = golden("nerf_grad_f7")
+    nc, nf = int(g["n_coarse"]), int(g["n_fine"])
+    sd_c = {k: v.clone().requires_grad_(True) for k, v in synth.state_dict("nerf", 50, True, 0.05).items()}
+    sd_f = {k: v.clone().requires_grad_(True) for k, v in synth.state_dict("nerf", 51, True, 0.05).items()}
+    tr = R.render_rays(torch.from_numpy(g["rays"]), 2.0, 6.0, fields.make_field("nerf", sd_c),
+                       fields.make_field("nerf", sd_f), nc, nf, torch.from_numpy(g["t_rand"]))
+    tgt = torch.from_numpy(g["target"])
+    loss = sum(torch.mean((rgb - tgt[:, :3]) ** 2) + 0.1 * torch.mean((acc - tgt[:, 3]) ** 2)
+               for rgb, acc in ((tr.rgb_f, tr.acc_f), (tr.rgb_c, tr.acc_c)))
+    close(loss.detach(), g["loss"], 1e-6)
+    loss.backward()
+    _check_grads(g, "coarse.", list(sd_c.items()))
+    _check_grads(g, "fine.", list(sd_f.items()))
