@@ -1,0 +1,127 @@
+/*
+ * mi_render.h - C ABI of libmirender.so: the MI355X (gfx950) implementation of the
+ * ray-march -> field-MLP -> alpha-composite path of JeffreyXiang/MSRA-practice-project.
+ *
+ * The reference has NO plugin/FFI layer: its boundary is the Python
+ * module namespace `render` (nerf/render.py, pi_GAN/render.py).  Each entry point below
+ * therefore cites the reference *Python function* whose device work it replaces; the
+ * Python drop-in modules (msra-practice-project_amd/nerf/render.py, .../pi_GAN/render.py)
+ * keep the reference call surface and bind these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - no allocation, no synchronisation inside: callers pass outputs and workspace;
+ *   - return 0 on success, negative MI_E* on error; mi_last_error() gives the message
+ *     (thread-local);
+ *   - all launches are asynchronous on `stream`.
+ */
+#ifndef MI_RENDER_H
+#define MI_RENDER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)   /* bad argument (shape, kind, null pointer) */
+#define MI_EHIP (-2)     /* HIP runtime error at launch */
+
+/* Field MLP kinds (state-dict layouts: SURVEY.md §8a a6-a8). */
+#define MI_FIELD_NERF 0                   /* nerf/nerf.py:52-94   NeRF            */
+#define MI_FIELD_SIREN_NERF 1             /* nerf/nerf.py:120-170 SirenNeRF       */
+#define MI_FIELD_FILM_SIREN_NERF 2        /* pi_GAN/modules.py:70-118 use_dir=True  */
+#define MI_FIELD_FILM_SIREN_NERF_NODIR 3  /* pi_GAN/modules.py:70-118 use_dir=False */
+#define MI_FIELD_TINY_NERF 4              /* build-defined 4-layer net for BASELINE C1 */
+#define MI_FIELD_KINDS 5
+
+/* Library / build identification. */
+int mi_abi_version(void);
+const char* mi_last_error(void);
+
+/* ---- field weights -------------------------------------------------------------- */
+
+/* Number of (weight, bias) tensors the kind's state dict holds, in forward order
+ * (weight_0, bias_0, weight_1, bias_1, ...). */
+int mi_field_num_params(int kind);
+/* Floats in the packed MFMA-ordered weight stream of the kind. */
+int64_t mi_field_packed_floats(int kind);
+/* Multiply-accumulates of the kind's linear layers per point (roofline accounting). */
+int64_t mi_field_macs(int kind);
+/* Repack torch-layout parameters ([out,in] row-major weights, [out] biases; `params` is a
+ * HOST array of n_params device pointers in state-dict order) into the packed stream the
+ * fused MLP kernel consumes.  Replaces nothing in the reference: it is the hand-off from
+ * nn.Module parameters (nerf/nerf.py:59-73, pi_GAN/modules.py:76-94) to the kernel and is
+ * called whenever the optimiser has changed the weights. */
+int mi_field_pack(int kind, const float* const* params, int n_params, float* packed, void* stream);
+
+/* ---- fused field MLP forward ---------------------------------------------------- */
+
+/* network(inputs[M,6]) -> [M,4] = (r,g,b,sigma): replaces the model call inside
+ * run_network (nerf/render.py:72-74) for a known kind.
+ *   x      [n_groups*points_per_group, 6]  (xyz, view_dir)
+ *   film   [n_groups, 9, 512] FiLM table (gamma|beta per layer; pi_GAN/modules.py:96-99)
+ *          for FILM kinds, else NULL; group g uses film[g]
+ *   out    [n_groups*points_per_group, 4] */
+int mi_field_eval_points(int kind, const float* packed, const float* film, const float* x,
+                         int64_t n_groups, int64_t points_per_group, float* out, void* stream);
+
+/* run_network fused with point generation (nerf/render.py:134-135 / :143-144):
+ * pts = o + d*z, view = d/|d|, raw = network([pts, view]).
+ *   rays   [n_groups*rays_per_group, 2, 3] (origin, direction)
+ *   z      [n_groups*rays_per_group, S]
+ *   raw    [n_groups*rays_per_group, S, 4] */
+int mi_field_eval_rays(int kind, const float* packed, const float* film, const float* rays,
+                       const float* z, int64_t n_groups, int64_t rays_per_group, int n_samples,
+                       float* raw, void* stream);
+
+/* ---- sampling / compositing stages ---------------------------------------------- */
+
+/* get_rays (nerf/render.py:7-23) on device, written in render_image's ray-list order
+ * (render.py:151-154): rays[ray0 .. ray0+n) of the H*W list, c2w = 12 floats (3x4 row-major,
+ * HOST pointer).  compute_f64 = 0 reproduces NumPy with a Python-float focal (all fp32);
+ * compute_f64 = 1 reproduces an np.float64 focal (pi_GAN/modules.py:127: fp64 math, rounded to
+ * fp32 at the end).  out rays [n,2,3]. */
+int mi_gen_rays(int width, int height, double focal, const float* c2w_host, int64_t ray0, int64_t n,
+                float* rays, int compute_f64, void* stream);
+
+/* stratified depths (nerf/render.py:123-132): z = lower + (upper-lower)*t_rand.
+ * z_lin  [Nc] optional table = linspace(near,far,Nc) (pass torch.linspace's CPU output for
+ *        bit parity with the CPU reference; NULL = ATen's scalar formula computed in-kernel)
+ * t_rand [n,Nc] device pointer, or NULL to draw U[0,1) from Philox4x32-10 keyed by
+ *        (seed, ray index, sample index).  out z [n,Nc]. */
+int mi_sample_coarse(int64_t n, float near_, float far_, int n_coarse, const float* z_lin,
+                     const float* t_rand, uint64_t seed, float* z, void* stream);
+
+/* raw_to_outputs (nerf/render.py:78-103).  raw [n,S,4], z [n,S], rays [n,2,3] (direction
+ * used for |d|).  out rgb [n,3], depth [n], acc [n], weights [n,S] (weights may be NULL). */
+int mi_composite(int64_t n, int n_samples, const float* raw, const float* z, const float* rays,
+                 float* rgb, float* depth, float* acc, float* weights, void* stream);
+
+/* sample_pdf + sort (nerf/render.py:140-142): bins = mids of linspace(near,far,Nc),
+ * weights[...,1:-1] of the coarse pass, deterministic u = linspace(0,1,Nf), merged with
+ * the coarse depths and sorted.  z_lin [Nc] / u_lin [Nf]: optional tables as above.
+ * out z_fine [n,Nc+Nf]; z_samples [n,Nf] optional (NULL). */
+int mi_sample_fine(int64_t n, float near_, float far_, int n_coarse, int n_fine, const float* z_lin,
+                   const float* u_lin, const float* z_coarse, const float* weights, float* z_samples,
+                   float* z_fine, void* stream);
+
+/* ---- whole path ----------------------------------------------------------------- */
+
+/* render_rays (nerf/render.py:106-147) for known field kinds, all stages on `stream`.
+ *   rays [n,2,3]; n = n_groups*rays_per_group; film tables as in mi_field_eval_rays
+ *   outs: rgb_c[n,3] depth_c[n] acc_c[n] rgb_f[n,3] depth_f[n] acc_f[n]
+ *   workspace: mi_render_workspace_bytes(n, Nc, Nf) bytes */
+int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine);
+int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, const float* packed_fine,
+                   const float* film, const float* rays, int64_t n_groups, int64_t rays_per_group,
+                   float near_, float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin,
+                   const float* t_rand, uint64_t seed, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f,
+                   void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_RENDER_H */

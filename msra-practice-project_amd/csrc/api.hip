@@ -1,0 +1,168 @@
+// api.hip - extern "C" surface of libmirender.so (see include/mi_render.h).
+// Argument validation lives here; kernels assume validated shapes.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/mi_render.h"
+#include "field_layout.h"
+#include "mi_common.h"
+
+namespace mi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MI_EHIP;
+    }
+    return MI_OK;
+}
+
+// implemented in field_mlp.hip / render_stages.hip
+const PackTable* host_table(int kind);
+static const int kNumLayers[MI_FIELD_KINDS] = {12, 12, 11, 11, 7};
+// multiply-accumulates of the linear layers per point (a6, a7, a8)
+static const int64_t kMacs[MI_FIELD_KINDS] = {591488, 559616, 526848, 526080, 248448};
+
+static bool bad_kind(int kind) {
+    if (kind < 0 || kind >= MI_FIELD_KINDS) { set_error("unknown field kind %d", kind); return true; }
+    return false;
+}
+static bool is_film(int kind) { return kind == MI_FIELD_FILM_SIREN_NERF || kind == MI_FIELD_FILM_SIREN_NERF_NODIR; }
+
+static int eval_common(int kind, const float* packed, const float* film, const float* a, const float* z,
+                       int64_t n_groups, int64_t ppg, int64_t rpg, int S, int mode, float* out, hipStream_t s) {
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (!packed || !a || !out || (mode == 1 && !z)) { set_error("null pointer argument"); return MI_EINVAL; }
+    if (is_film(kind) && !film) { set_error("FiLM kind needs a film table"); return MI_EINVAL; }
+    if (n_groups < 0 || ppg < 0) { set_error("negative size"); return MI_EINVAL; }
+    if (n_groups == 0 || ppg == 0) return MI_OK;
+    MlpArgs args;
+    args.packed = packed; args.film = is_film(kind) ? film : nullptr; args.a = a; args.z = z; args.out = out;
+    args.points_per_group = ppg; args.rays_per_group = rpg; args.tiles_per_group = (ppg + 127) / 128;
+    args.n_samples = S; args.mode = mode;
+    return launch_mlp(kind, args, n_groups, s);
+}
+
+}  // namespace mi
+
+using namespace mi;
+
+extern "C" {
+
+int mi_abi_version(void) { return 1; }
+const char* mi_last_error(void) { return g_err; }
+
+int mi_field_num_params(int kind) { return bad_kind(kind) ? MI_EINVAL : 2 * kNumLayers[kind]; }
+int64_t mi_field_packed_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : packed_floats(*host_table(kind)); }
+int64_t mi_field_macs(int kind) { return bad_kind(kind) ? MI_EINVAL : kMacs[kind]; }
+
+int mi_field_pack(int kind, const float* const* params, int n_params, float* packed, void* stream) {
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (!params || !packed) { set_error("null pointer argument"); return MI_EINVAL; }
+    if (n_params != 2 * kNumLayers[kind]) {
+        set_error("kind %d expects %d parameter tensors, got %d", kind, 2 * kNumLayers[kind], n_params);
+        return MI_EINVAL;
+    }
+    for (int i = 0; i < n_params; ++i)
+        if (!params[i]) { set_error("parameter %d is null", i); return MI_EINVAL; }
+    return launch_pack(kind, params, n_params, packed, (hipStream_t)stream);
+}
+
+int mi_field_eval_points(int kind, const float* packed, const float* film, const float* x, int64_t n_groups,
+                         int64_t points_per_group, float* out, void* stream) {
+    return eval_common(kind, packed, film, x, nullptr, n_groups, points_per_group, 0, 1, 0, out, (hipStream_t)stream);
+}
+
+int mi_field_eval_rays(int kind, const float* packed, const float* film, const float* rays, const float* z,
+                       int64_t n_groups, int64_t rays_per_group, int n_samples, float* raw, void* stream) {
+    if (n_samples <= 0) { set_error("n_samples must be positive"); return MI_EINVAL; }
+    return eval_common(kind, packed, film, rays, z, n_groups, rays_per_group * n_samples, rays_per_group, n_samples, 1,
+                       raw, (hipStream_t)stream);
+}
+
+int mi_gen_rays(int width, int height, double focal, const float* c2w_host, int64_t ray0, int64_t n, float* rays,
+                int compute_f64, void* stream) {
+    if (width <= 0 || height <= 0 || !c2w_host || !rays || ray0 < 0 || n < 0 || ray0 + n > (int64_t)width * height) {
+        set_error("mi_gen_rays: bad arguments");
+        return MI_EINVAL;
+    }
+    return launch_gen_rays(width, height, focal, c2w_host, ray0, n, rays, compute_f64, (hipStream_t)stream);
+}
+
+int mi_sample_coarse(int64_t n, float near_, float far_, int n_coarse, const float* z_lin, const float* t_rand,
+                     uint64_t seed, float* z, void* stream) {
+    if (n < 0 || n_coarse < 1 || !z) { set_error("mi_sample_coarse: bad arguments"); return MI_EINVAL; }
+    return launch_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, z, (hipStream_t)stream);
+}
+
+int mi_composite(int64_t n, int n_samples, const float* raw, const float* z, const float* rays, float* rgb,
+                 float* depth, float* acc, float* weights, void* stream) {
+    if (n < 0 || n_samples < 1 || !raw || !z || !rays || !rgb || !depth || !acc) {
+        set_error("mi_composite: bad arguments");
+        return MI_EINVAL;
+    }
+    return launch_composite(n, n_samples, raw, z, rays, rgb, depth, acc, weights, (hipStream_t)stream);
+}
+
+int mi_sample_fine(int64_t n, float near_, float far_, int n_coarse, int n_fine, const float* z_lin,
+                   const float* u_lin, const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
+                   void* stream) {
+    // sample_pdf is called with mids (Nc-1 bins) and weights[1:-1] (Nc-2): needs Nc >= 3
+    if (n < 0 || n_coarse < 3 || n_fine < 0 || !z_coarse || !weights || !z_fine) {
+        set_error("mi_sample_fine: bad arguments (need Nc >= 3)");
+        return MI_EINVAL;
+    }
+    return launch_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_coarse, weights, z_samples, z_fine,
+                              (hipStream_t)stream);
+}
+
+int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine) {
+    const int64_t S = (int64_t)n_coarse + n_fine;
+    // z_c[n,Nc] raw_c[n,Nc,4] w_c[n,Nc] z_f[n,S] raw_f[n,S,4]; each region 256-byte aligned
+    int64_t f = 0;
+    auto add = [&](int64_t x) { f += (x + 63) / 64 * 64; };
+    add(n * n_coarse); add(n * n_coarse * 4); add(n * n_coarse); add(n * S); add(n * S * 4);
+    return f * (int64_t)sizeof(float);
+}
+
+int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, const float* packed_fine,
+                   const float* film, const float* rays, int64_t n_groups, int64_t rays_per_group, float near_,
+                   float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin, const float* t_rand,
+                   uint64_t seed, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f, float* depth_f,
+                   float* acc_f, void* workspace, void* stream) {
+    if (!workspace || !rays || !rgb_c || !depth_c || !acc_c || !rgb_f || !depth_f || !acc_f) {
+        set_error("mi_render_rays: null pointer argument");
+        return MI_EINVAL;
+    }
+    const int64_t n = n_groups * rays_per_group;
+    const int S = n_coarse + n_fine;
+    float* ws = (float*)workspace;
+    auto take = [&](int64_t x) { float* p = ws; ws += (x + 63) / 64 * 64; return p; };
+    float* z_c = take(n * n_coarse);
+    float* raw_c = take(n * n_coarse * 4);
+    float* w_c = take(n * n_coarse);
+    float* z_f = take(n * (int64_t)S);
+    float* raw_f = take(n * (int64_t)S * 4);
+    int rc;
+    if ((rc = mi_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, z_c, stream))) return rc;
+    if ((rc = mi_field_eval_rays(kind_coarse, packed_coarse, film, rays, z_c, n_groups, rays_per_group, n_coarse, raw_c,
+                                 stream))) return rc;
+    if ((rc = mi_composite(n, n_coarse, raw_c, z_c, rays, rgb_c, depth_c, acc_c, w_c, stream))) return rc;
+    if ((rc = mi_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_c, w_c, nullptr, z_f, stream))) return rc;
+    if ((rc = mi_field_eval_rays(kind_fine, packed_fine, film, rays, z_f, n_groups, rays_per_group, S, raw_f, stream)))
+        return rc;
+    return mi_composite(n, S, raw_f, z_f, rays, rgb_f, depth_f, acc_f, nullptr, stream);
+}
+
+}  // extern "C"

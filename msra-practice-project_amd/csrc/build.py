@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Build libmirender.so for gfx950 with hipcc (in-tree, no JIT cache).
+
+    python msra-practice-project_amd/csrc/build.py [--force]
+
+Outputs msra-practice-project_amd/mirender/libmirender.so next to the Python binding so it
+travels to the GPU box with the source snapshot.  hipcc cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+OUT = os.path.join(PKG, "mirender", "libmirender.so")
+OBJ = os.path.join(HERE, "_obj")
+ARCH = "gfx950"
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+SOURCES = {
+    "field_mlp.hip": [],
+    # un-fused mul/add like the torch / NumPy ops these kernels restate
+    "render_stages.hip": ["-ffp-contract=off"],
+    "api.hip": [],
+}
+HEADERS = ["field_layout.h", "mi_common.h", os.path.join("..", "..", "include", "mi_render.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    objs = []
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc, *COMMON, *extra, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(OUT, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

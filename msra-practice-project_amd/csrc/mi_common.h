@@ -1,0 +1,52 @@
+// mi_common.h - small shared helpers for the libmirender kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+#include <utility>
+
+namespace mi {
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int,0>) ... f(integral_constant<int,N-1>), fully unrolled at compile time
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// error plumbing for the C ABI (api.hip)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// arguments of the fused field-MLP kernels (field_mlp.hip)
+struct MlpArgs {
+    const float* packed;    // packed weight stream (field_layout.h)
+    const float* film;      // [groups][9][512] or null
+    const float* a;         // points x[M,6] (mode 0) or rays [N,2,3] (mode 1)
+    const float* z;         // [N,S] (mode 1)
+    float* out;             // [M,4]
+    int64_t points_per_group;
+    int64_t rays_per_group;
+    int64_t tiles_per_group;
+    int n_samples;
+    int mode;
+};
+
+// host launchers (field_mlp.hip, render_stages.hip)
+int launch_pack(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream);
+int launch_mlp(int kind, const MlpArgs& a, int64_t n_groups, hipStream_t stream);
+int launch_gen_rays(int width, int height, double focal, const float* c2w, int64_t ray0, int64_t n, float* rays,
+                    int compute_f64, hipStream_t stream);
+int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float* z_lin, const float* t_rand,
+                         uint64_t seed, float* z, hipStream_t stream);
+int launch_composite(int64_t n, int S, const float* raw, const float* z, const float* rays, float* rgb, float* depth,
+                     float* acc, float* weights, hipStream_t stream);
+int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,
+                       const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
+                       hipStream_t stream);
+
+}  // namespace mi

@@ -1,0 +1,283 @@
+// render_stages.hip - the HBM-bound stages around the fused field MLP (gfx950).
+//
+//   gen_rays_kernel       get_rays                       reference nerf/render.py:7-23
+//   sample_coarse_kernel  stratified depths              nerf/render.py:123-132
+//   composite_kernel      raw_to_outputs                 nerf/render.py:78-103
+//   sample_fine_kernel    sample_pdf + detach/cat/sort   nerf/render.py:27-56, 140-142
+//
+// All arithmetic is fp32 in the reference's operation order (this file is compiled with
+// -ffp-contract=off so a*b+c stays two roundings like the un-fused torch/NumPy ops).
+// These stages move 20-30 B per sample against 1.2 MFLOP per sample in the MLP: they are
+// coalesced streaming kernels, not worth fusing further.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_common.h"
+
+namespace mi {
+
+// ---------------------------------------------------------------------------------------
+// get_rays: ray `idx` of the row-major H*W list; dirs = ((i-W/2)/f, -(j-H/2)/f, -1);
+// d = sum_k dirs[k]*c2w[c][k] accumulated left to right like np.sum over 3 elements.
+// ---------------------------------------------------------------------------------------
+struct Cam { float m[12]; };
+
+// T = float reproduces NumPy when `focal` is a Python float (weak scalar -> all-fp32 math);
+// T = double reproduces it when `focal` is an np.float64 scalar (pi_GAN/modules.py:127: the
+// whole expression is promoted to fp64 and rounded to fp32 by torch.tensor(..., dtype=float)).
+template <class T>
+__global__ void gen_rays_kernel(int width, T half_w, T half_h, T focal, Cam cam, int64_t ray0, int64_t n,
+                                float* __restrict__ rays) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int64_t idx = ray0 + t;
+    const T i = (T)(float)(idx % width), j = (T)(float)(idx / width);
+    const T d0 = (i - half_w) / focal;
+    const T d1 = -((j - half_h) / focal);
+    const T d2 = (T)-1;
+    float* o = rays + t * 6;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        o[c] = cam.m[4 * c + 3];
+        o[3 + c] = (float)((d0 * (T)cam.m[4 * c + 0] + d1 * (T)cam.m[4 * c + 1]) + d2 * (T)cam.m[4 * c + 2]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// linspace(start, end, steps)[i] as ATen's scalar formula (RangeFactories: symmetric halves).
+// The host may instead pass the table torch.linspace produced so z matches the CPU oracle
+// bit for bit (its vectorised path differs from this formula by 1 ulp on a few entries).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_at(float start, float end, int steps, int i) {
+    if (steps <= 1) return start;
+    const float step = (end - start) / (float)(steps - 1);
+    return i < steps / 2 ? start + step * (float)i : end - step * (float)(steps - i - 1);
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = (ray_lo, ray_hi, sample>>2, 0), key = seed.
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ray, uint32_t sample) {
+    uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32), c2 = sample >> 2, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t s = sample & 3;
+    return s == 0 ? c0 : (s == 1 ? c1 : (s == 2 ? c2 : c3));
+}
+
+__global__ void sample_coarse_kernel(int64_t n, float near_, float far_, int nc, const float* __restrict__ z_lin,
+                                     const float* __restrict__ t_rand, uint64_t seed, float* __restrict__ z) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * nc) return;
+    const int k = (int)(t % nc);
+    const int64_t ray = t / nc;
+    auto lin = [&](int i) { return z_lin ? z_lin[i] : linspace_at(near_, far_, nc, i); };
+    const float zk = lin(k);
+    const float lower = k == 0 ? zk : 0.5f * (zk + lin(k - 1));
+    const float upper = k == nc - 1 ? zk : 0.5f * (lin(k + 1) + zk);
+    const float u = t_rand ? t_rand[t] : (float)(philox_u32(seed, (uint64_t)ray, (uint32_t)k) >> 8) * 0x1p-24f;
+    z[t] = lower + (upper - lower) * u;
+}
+
+// ---------------------------------------------------------------------------------------
+// composite: G lanes per ray (G = 16/32/64), lane = sample, passes of G samples with the
+// transmittance carried between passes.  alpha = 1-exp(-sigma*delta*|d|),
+// T = exclusive prod(1-alpha+1e-10), w = alpha*T; rgb = sum w c + (1-acc) (white background).
+// ---------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void composite_kernel(int64_t n, int S, const float* __restrict__ raw,
+                                                        const float* __restrict__ z, const float* __restrict__ rays,
+                                                        float* __restrict__ rgb, float* __restrict__ depth,
+                                                        float* __restrict__ acc, float* __restrict__ weights) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (G - 1);
+    const int64_t groups_per_block = 256 / G;
+    const int64_t ray = (int64_t)blockIdx.x * groups_per_block + threadIdx.x / G;
+    const bool live = ray < n;
+    const int64_t rc = live ? ray : n - 1;
+    const float* rd = rays + rc * 6 + 3;
+    const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+    float T = 1.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    for (int k0 = 0; k0 < S; k0 += G) {
+        const int k = k0 + sub;
+        const bool in = k < S;
+        const int kc = in ? k : S - 1;
+        const float4 c = reinterpret_cast<const float4*>(raw)[rc * S + kc];
+        const float zk = z[rc * S + kc];
+        const float zn = kc + 1 < S ? z[rc * S + kc + 1] : 0.f;
+        float delta = kc + 1 < S ? zn - zk : 1e10f;
+        delta = delta * nrm;
+        const float alpha = in ? 1.0f - expf(-c.w * delta) : 0.f;
+        const float f = in ? (1.0f - alpha) + 1e-10f : 1.f;
+        // inclusive product scan inside the G-lane group
+        float p = f;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const float q = __shfl_up(p, o, G);
+            if (sub >= o) p *= q;
+        }
+        float excl = __shfl_up(p, 1, G);
+        if (sub == 0) excl = 1.f;
+        const float w = alpha * (T * excl);
+        T = T * __shfl(p, G - 1, G);
+        if (in) {
+            sr += w * c.x; sg += w * c.y; sb += w * c.z; sd += w * zk; sa += w;
+            if (weights && live) weights[rc * S + k] = w;
+        }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        sr += __shfl_xor(sr, o, G); sg += __shfl_xor(sg, o, G); sb += __shfl_xor(sb, o, G);
+        sd += __shfl_xor(sd, o, G); sa += __shfl_xor(sa, o, G);
+    }
+    if (live && sub == 0) {
+        const float bg = 1.0f - sa;
+        rgb[ray * 3 + 0] = sr + bg; rgb[ray * 3 + 1] = sg + bg; rgb[ray * 3 + 2] = sb + bg;
+        depth[ray] = sd;
+        acc[ray] = sa;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// sample_fine: one wave per ray.  bins = mids of the coarse linspace, w = weights[1:-1]+1e-5,
+// pdf = w/sum(w), cdf = [0, cumsum(pdf)] accumulated SEQUENTIALLY per entry like torch.cumsum
+// on CPU; u = linspace(0,1,Nf); idx = #(cdf <= u) (searchsorted right=True); guarded lerp;
+// then z_fine = sort(cat(z_coarse, z_samples)) by full rank counting (no sortedness assumed).
+// LDS per wave: cdf[Nc] | bins[Nc] | zall[Nc+Nf]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_, float far_, int nc, int nf,
+                                                          const float* __restrict__ z_lin,
+                                                          const float* __restrict__ u_lin,
+                                                          const float* __restrict__ z_coarse,
+                                                          const float* __restrict__ weights,
+                                                          float* __restrict__ z_samples, float* __restrict__ z_fine) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = nc + nf;
+    const int per_wave = 2 * nc + S;
+    float* cdf = smem + wave * per_wave;
+    float* bins = cdf + nc;
+    float* zall = bins + nc;
+    const int nb = nc - 1;      // bins / cdf entries
+    const int nw = nc - 2;      // interior weights
+    auto lin = [&](int i) { return z_lin ? z_lin[i] : linspace_at(near_, far_, nc, i); };
+    for (int j = lane; j < nb; j += 64) bins[j] = 0.5f * (lin(j + 1) + lin(j));
+
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + wave; ray < n; ray += (int64_t)gridDim.x * 4) {
+        const float* wr = weights + ray * nc;
+        const float* zc = z_coarse + ray * nc;
+        // sum of (w + 1e-5)
+        float part = 0.f;
+        for (int j = lane; j < nw; j += 64) part += wr[j + 1] + 1e-5f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        const float total = part;
+        // pdf into zall (scratch), then per-entry sequential prefix = torch.cumsum order
+        for (int j = lane; j < nw; j += 64) zall[j] = (wr[j + 1] + 1e-5f) / total;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int j = lane; j < nb; j += 64) {
+            float s = 0.f;
+            for (int i = 0; i < j; ++i) s = i == 0 ? zall[0] : s + zall[i];
+            cdf[j] = s;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // coarse depths first, then inverse-CDF samples
+        for (int j = lane; j < nc; j += 64) zall[j] = zc[j];
+        for (int s = lane; s < nf; s += 64) {
+            const float u = u_lin ? u_lin[s] : linspace_at(0.f, 1.f, nf, s);
+            int lo_i = 0, hi_i = nb;                 // count of cdf entries <= u  (cdf ascending)
+            while (lo_i < hi_i) {
+                const int mid = (lo_i + hi_i) >> 1;
+                if (cdf[mid] <= u) lo_i = mid + 1; else hi_i = mid;
+            }
+            const int idx = lo_i;
+            const int below = idx - 1 > 0 ? idx - 1 : 0;
+            const int above = idx < nb - 1 ? idx : nb - 1;
+            const float c0 = cdf[below], c1 = cdf[above];
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.f;
+            const float t = (u - c0) / denom;
+            const float b0 = bins[below], b1 = bins[above];
+            const float zs = b0 + t * (b1 - b0);
+            zall[nc + s] = zs;
+            if (z_samples) z_samples[ray * nf + s] = zs;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // rank sort: position = #(smaller) + #(equal with lower index)
+        for (int e = lane; e < S; e += 64) {
+            const float v = zall[e];
+            int rank = 0;
+            for (int i = 0; i < S; ++i) {
+                const float o = zall[i];
+                rank += (o < v) || (o == v && i < e);
+            }
+            z_fine[ray * S + rank] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------------
+int launch_gen_rays(int width, int height, double focal, const float* c2w, int64_t ray0, int64_t n, float* rays,
+                    int compute_f64, hipStream_t stream) {
+    if (n <= 0) return 0;
+    Cam cam;
+    for (int i = 0; i < 12; ++i) cam.m[i] = c2w[i];
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    if (compute_f64)
+        hipLaunchKernelGGL(gen_rays_kernel<double>, dim3(blocks), dim3(256), 0, stream, width, width * 0.5,
+                           height * 0.5, focal, cam, ray0, n, rays);
+    else
+        hipLaunchKernelGGL(gen_rays_kernel<float>, dim3(blocks), dim3(256), 0, stream, width, (float)(width * 0.5),
+                           (float)(height * 0.5), (float)focal, cam, ray0, n, rays);
+    return check_launch("gen_rays");
+}
+
+int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float* z_lin, const float* t_rand,
+                         uint64_t seed, float* z, hipStream_t stream) {
+    if (n <= 0) return 0;
+    const int64_t total = n * nc;
+    hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, near_,
+                       far_, nc, z_lin, t_rand, seed, z);
+    return check_launch("sample_coarse");
+}
+
+int launch_composite(int64_t n, int S, const float* raw, const float* z, const float* rays, float* rgb, float* depth,
+                     float* acc, float* weights, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if (S > 32) {
+        hipLaunchKernelGGL(composite_kernel<64>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, n, S, raw, z,
+                           rays, rgb, depth, acc, weights);
+    } else if (S > 16) {
+        hipLaunchKernelGGL(composite_kernel<32>, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, stream, n, S, raw, z,
+                           rays, rgb, depth, acc, weights);
+    } else {
+        hipLaunchKernelGGL(composite_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, stream, n, S, raw, z,
+                           rays, rgb, depth, acc, weights);
+    }
+    return check_launch("composite");
+}
+
+int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,
+                       const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
+                       hipStream_t stream) {
+    if (n <= 0) return 0;
+    const size_t lds = (size_t)4 * (2 * nc + nc + nf) * sizeof(float);
+    if (lds > 160 * 1024) { set_error("sample_fine: Nc=%d Nf=%d exceed LDS", nc, nf); return -1; }
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(sample_fine_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, n, near_, far_, nc, nf,
+                       z_lin, u_lin, z_coarse, weights, z_samples, z_fine);
+    return check_launch("sample_fine");
+}
+
+}  // namespace mi

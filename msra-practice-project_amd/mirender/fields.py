@@ -1,0 +1,300 @@
+"""Radiance-field models on the fused HIP MLP kernel.
+
+Two jobs:
+
+1. Recognise the reference's model objects (nerf/nerf.py NeRF / SirenNeRF, pi_GAN/modules.py
+   FilmSirenNeRF) by their parameter layout, so `render_rays(rays, near, far, coarse_model,
+   fine_model, ...)` keeps the reference call surface (nerf/render.py:106) while the
+   `network(inputs)` call of run_network (render.py:72-74) runs in one fused kernel.
+   Parameters are read AT CALL TIME (the optimiser mutates them in place) and repacked into
+   the MFMA-ordered stream only when a parameter's version counter has changed.
+
+2. Provide the same model families as nn.Modules with identical state-dict keys
+   (checkpoints of the reference load with load_state_dict) whose forward([M,6]) -> [M,4]
+   is the fused kernel.  There is no PyTorch/CPU forward here on purpose: without the HIP
+   library these modules raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NERF, SIREN_NERF, FILM_SIREN_NERF, FILM_SIREN_NERF_NODIR, TINY_NERF = range(5)
+KIND_NAMES = {NERF: "nerf", SIREN_NERF: "siren_nerf", FILM_SIREN_NERF: "film_siren_nerf",
+              FILM_SIREN_NERF_NODIR: "film_siren_nerf_nodir", TINY_NERF: "tiny_nerf"}
+
+# (key, (out, in)) per linear layer in the order the C ABI expects (mi_field_pack)
+_HID = [(f"hidden_layers.{i}", (256, 256)) for i in range(7)]
+SPECS = {
+    NERF: [("layers_pos.0", (256, 60))] + [(f"layers_pos.{i}", (256, 256)) for i in (1, 2, 3, 4)]
+          + [("layers_pos.5", (256, 316)), ("layers_pos.6", (256, 256)), ("layers_pos.7", (256, 256)),
+             ("layers_dir.0", (256, 256)), ("layers_dir.1", (128, 280)),
+             ("output_layer_sigma", (1, 256)), ("output_layer_rgb", (3, 128))],
+    SIREN_NERF: [("layers_pos.0", (256, 3))] + [(f"layers_pos.{i}", (256, 256)) for i in (1, 2, 3, 4)]
+                + [("layers_pos.5", (256, 259)), ("layers_pos.6", (256, 256)), ("layers_pos.7", (256, 256)),
+                   ("layers_dir.0", (256, 256)), ("layers_dir.1", (128, 259)),
+                   ("output_layer_sigma", (1, 256)), ("output_layer_rgb", (3, 128))],
+    FILM_SIREN_NERF: [("input_layer", (256, 3))] + _HID
+                     + [("output_layer_sigma.0", (1, 256)), ("hidden_layer_rgb", (256, 259)),
+                        ("output_layer_rgb.0", (3, 256))],
+    FILM_SIREN_NERF_NODIR: [("input_layer", (256, 3))] + _HID
+                           + [("output_layer_sigma.0", (1, 256)), ("hidden_layer_rgb", (256, 256)),
+                              ("output_layer_rgb.0", (3, 256))],
+    TINY_NERF: [("layers_pos.0", (256, 60))] + [(f"layers_pos.{i}", (256, 256)) for i in (1, 2, 3)]
+               + [("layers_dir.0", (128, 280)), ("output_layer_sigma", (1, 256)), ("output_layer_rgb", (3, 128))],
+}
+MACS = {k: sum(o * i for _, (o, i) in v) for k, v in SPECS.items()}
+FLOPS_PER_POINT = {k: 2 * v for k, v in MACS.items()}   # 2 x MACs of the linear layers
+
+
+def is_film(kind: int) -> bool:
+    return kind in (FILM_SIREN_NERF, FILM_SIREN_NERF_NODIR)
+
+
+def _shapes(kind):
+    out = {}
+    for key, (o, i) in SPECS[kind]:
+        out[key + ".weight"] = (o, i)
+        out[key + ".bias"] = (o,)
+    return out
+
+
+def detect_kind(named_params: dict) -> int | None:
+    """Match a {name: tensor} mapping against the known layouts (exact key set and shapes)."""
+    got = {k: tuple(v.shape) for k, v in named_params.items()}
+    for kind in SPECS:
+        if got == _shapes(kind):
+            return kind
+    return None
+
+
+class PackedField:
+    """Packed MFMA-ordered weights of one model, refreshed lazily from its live parameters."""
+
+    def __init__(self, kind: int, params: list):
+        self.kind = kind
+        self.params = params                      # live tensors, state-dict order (w0,b0,w1,b1,...)
+        self.device = params[0].device
+        lib = _lib.load()
+        n = lib.mi_field_packed_floats(kind)
+        self.packed = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._versions = None
+        self._ptrs = None
+
+    def refresh(self):
+        vers = tuple((p.data_ptr(), p._version) for p in self.params)
+        if vers == self._versions:
+            return self.packed
+        lib = _lib.load()
+        srcs = []
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != self.device:
+                raise _lib.MiRenderError("field parameters must be fp32 on one device")
+            srcs.append(p.detach() if p.is_contiguous() else p.detach().contiguous())
+        arr = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mi_field_pack(self.kind, arr, len(srcs), _lib.ptr(self.packed),
+                                         _lib.stream_ptr(self.device)), "mi_field_pack")
+        self._keep = srcs
+        self._versions = vers
+        return self.packed
+
+
+_field_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def as_packed_field(model) -> PackedField | None:
+    """PackedField for a recognised nn.Module (reference class or ours), else None."""
+    if isinstance(model, PackedField):
+        return model
+    if not isinstance(model, torch.nn.Module):
+        return None
+    pf = _field_cache.get(model)
+    if pf is None:
+        named = dict(model.named_parameters())
+        kind = detect_kind(named)
+        if kind is None:
+            _field_cache[model] = False
+            return None
+        if not next(iter(named.values())).is_cuda:
+            raise _lib.MiRenderError("the fused renderer needs the model on a ROCm device (model.cuda())")
+        params = []
+        for key, _ in SPECS[kind]:
+            params += [named[key + ".weight"], named[key + ".bias"]]
+        pf = PackedField(kind, params)
+        _field_cache[model] = pf
+    return pf or None
+
+
+def film_table(model) -> torch.Tensor:
+    """[1,9,512] FiLM table from FilmSirenNeRF.film_params (list of 9 (gamma, beta) pairs set by
+    set_film_params, pi_GAN/modules.py:96-99).  Raises ValueError like the reference
+    (modules.py:106-107) when unset."""
+    fp = getattr(model, "film_params", None)
+    if fp is None:
+        raise ValueError
+    if isinstance(fp, torch.Tensor):
+        return fp.reshape(-1, 9, 512)
+    return torch.cat([torch.cat([g.reshape(-1), b.reshape(-1)]) for g, b in fp]).reshape(1, 9, 512)
+
+
+def eval_points(pf: PackedField, x: torch.Tensor, film: torch.Tensor | None = None) -> torch.Tensor:
+    """network(x[M,6]) -> [M,4] on the fused kernel (replaces the model call at render.py:73)."""
+    lib = _lib.load()
+    if x.dim() != 2 or x.shape[1] != 6:
+        raise _lib.MiRenderError(f"expected inputs [M,6], got {tuple(x.shape)}")
+    x = x.detach().to(device=pf.device, dtype=torch.float32).contiguous()
+    out = torch.empty((x.shape[0], 4), dtype=torch.float32, device=pf.device)
+    groups, ppg = 1, x.shape[0]
+    if is_film(pf.kind):
+        if film is None:
+            raise ValueError
+        film = film.detach().to(device=pf.device, dtype=torch.float32).contiguous().reshape(-1, 9, 512)
+        groups = film.shape[0]
+        if x.shape[0] % groups:
+            raise _lib.MiRenderError("points must split evenly over the FiLM groups")
+        ppg = x.shape[0] // groups
+    with torch.cuda.device(pf.device):
+        _lib.check(lib.mi_field_eval_points(pf.kind, _lib.ptr(pf.refresh()), _lib.ptr(film), _lib.ptr(x), groups,
+                                            ppg, _lib.ptr(out), _lib.stream_ptr(pf.device)), "mi_field_eval_points")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# nn.Module families with the reference's state-dict layout and initialisers
+# ------------------------------------------------------------------------------------------
+class _FusedField(torch.nn.Module):
+    KIND = None
+
+    def __init__(self):
+        super().__init__()
+        for key, (o, i) in SPECS[self.KIND]:
+            self._register(key, torch.nn.Parameter(torch.empty(o, i)), torch.nn.Parameter(torch.zeros(o)))
+        self.reset_parameters()
+
+    def _register(self, key, w, b):
+        mod = self
+        for p in key.split("."):
+            if not hasattr(mod, p):
+                mod.add_module(p, torch.nn.Module())
+            mod = getattr(mod, p)
+        mod.weight, mod.bias = w, b
+
+    def _layer(self, key):
+        mod = self
+        for p in key.split("."):
+            mod = getattr(mod, p)
+        return mod
+
+    @property
+    def flops_per_point(self):
+        return FLOPS_PER_POINT[self.KIND]
+
+    def forward(self, input_tensor):
+        return eval_points(as_packed_field(self), input_tensor)
+
+
+def _xavier(w, gain):
+    torch.nn.init.xavier_uniform_(w, gain=gain)
+
+
+class NeRF(_FusedField):
+    """nerf/nerf.py:52-94 (PE(10)/PE(4), 8x256 ReLU, skip at layer 5)."""
+    KIND = NERF
+
+    def reset_parameters(self):
+        # Dense.reset_parameters nerf/nerf.py:25-28: xavier_uniform with the activation's gain, zero bias
+        for key, _ in SPECS[self.KIND]:
+            act = "relu"
+            if key == "output_layer_rgb":
+                act = "sigmoid"
+            if self.KIND == NERF and key == "layers_dir.0":
+                act = "linear"
+            _xavier(self._layer(key).weight, torch.nn.init.calculate_gain(act))
+            torch.nn.init.zeros_(self._layer(key).bias)
+
+
+class TinyNeRF(NeRF):
+    """Build-defined 4-layer variant for BASELINE config C1."""
+    KIND = TINY_NERF
+
+
+class SirenNeRF(_FusedField):
+    """nerf/nerf.py:120-170 (sin(30 .) layers on raw xyz / dir)."""
+    KIND = SIREN_NERF
+
+    def reset_parameters(self):
+        for key, (o, i) in SPECS[self.KIND]:
+            lay = self._layer(key)
+            if key in ("layers_dir.0", "output_layer_rgb"):
+                _xavier(lay.weight, 1.0)
+            elif key == "output_layer_sigma":
+                _xavier(lay.weight, math.sqrt(2.0))
+            else:  # Siren.reset_parameters nerf/nerf.py:114-117, first layer nerf/nerf.py:134
+                bound = 1 / 30 if key == "layers_pos.0" else math.sqrt(6 / i) / 30
+                torch.nn.init.uniform_(lay.weight, -bound, bound)
+            torch.nn.init.zeros_(lay.bias)
+
+
+class FilmSirenNeRF(_FusedField):
+    """pi_GAN/modules.py:70-118.  FiLM parameters are per-image state set by set_film_params
+    (modules.py:96-99) or passed to forward, as in the reference."""
+    KIND = FILM_SIREN_NERF
+
+    def __new__(cls, use_dir=True, **kw):
+        if cls is FilmSirenNeRF and not use_dir:
+            return super().__new__(FilmSirenNeRFNoDir)
+        return super().__new__(cls)
+
+    def __init__(self, use_dir=True, **kw):
+        super().__init__()
+        self.use_dir = use_dir
+        self.film_params = None
+
+    def reset_parameters(self):
+        for key, (o, i) in SPECS[self.KIND]:
+            lay = self._layer(key)
+            if key in ("output_layer_sigma.0", "output_layer_rgb.0"):   # torch.nn.Linear default
+                b = 1 / math.sqrt(i)
+                torch.nn.init.uniform_(lay.weight, -b, b)
+                torch.nn.init.uniform_(lay.bias, -b, b)
+            else:  # FilmSiren.reset_parameters pi_GAN/modules.py:27-31
+                wb = 1 / i if key == "input_layer" else math.sqrt(6 / i) / 30
+                torch.nn.init.uniform_(lay.weight, -wb, wb)
+                torch.nn.init.uniform_(lay.bias, -math.sqrt(1 / i), math.sqrt(1 / i))
+
+    def set_film_params(self, mapping_tensor):
+        self.film_params = [torch.chunk(mapping_tensor[i], 2) for i in range(mapping_tensor.shape[0])]
+
+    def forward(self, input_tensor, film_params=None):
+        if film_params is not None:
+            self.film_params = film_params
+        elif self.film_params is None:
+            raise ValueError
+        return eval_points(as_packed_field(self), input_tensor, film_table(self))
+
+
+class FilmSirenNeRFNoDir(FilmSirenNeRF):
+    KIND = FILM_SIREN_NERF_NODIR
+
+    def __init__(self, use_dir=False, **kw):
+        super().__init__(use_dir=False)
+
+
+def field_from_state_dict(sd: dict, device="cuda") -> torch.nn.Module:
+    """Build the matching fused module for a reference state dict (checkpoint interop)."""
+    kind = detect_kind(sd)
+    if kind is None:
+        raise _lib.MiRenderError("state dict does not match a known field layout")
+    cls = {NERF: NeRF, SIREN_NERF: SirenNeRF, FILM_SIREN_NERF: FilmSirenNeRF,
+           FILM_SIREN_NERF_NODIR: FilmSirenNeRFNoDir, TINY_NERF: TinyNeRF}[kind]
+    m = cls()
+    m.load_state_dict({k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
+                       for k, v in sd.items()})
+    return m.to(device)

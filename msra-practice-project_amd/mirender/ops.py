@@ -1,0 +1,168 @@
+"""Stage-level wrappers over the C ABI (one function per reference stage).
+
+Every function takes/returns torch tensors on a ROCm device and launches on the calling
+thread's current stream; nothing here computes in PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes
+import functools
+
+import numpy as np
+import torch
+
+from . import _lib
+from .fields import PackedField, is_film
+
+
+def _f32c(t, device):
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+@functools.lru_cache(maxsize=64)
+def _linspace_table(start: float, end: float, steps: int, device_str: str):
+    """torch.linspace evaluated on the CPU (as the reference's CPU path does: render.py:35,123) and
+    uploaded once, so depths match the CPU oracle bit for bit."""
+    return torch.linspace(start, end, steps=steps, dtype=torch.float32).to(device_str)
+
+
+def linspace_table(start, end, steps, device):
+    if steps <= 0:
+        return None
+    return _linspace_table(float(start), float(end), int(steps), str(device))
+
+
+def gen_rays(width: int, height: int, focal, c2w, device, ray0: int = 0, n: int | None = None) -> torch.Tensor:
+    """get_rays (nerf/render.py:7-23) generated on the device in render_image's flattened order
+    (render.py:151-154).  Returns rays [n,2,3]."""
+    lib = _lib.load()
+    n = width * height - ray0 if n is None else n
+    c2w = np.ascontiguousarray(np.asarray(c2w)[:3, :4], dtype=np.float32)
+    # NumPy >= 2 promotion: an np.float64 focal promotes the whole expression to fp64 (pi_GAN/modules.py:127),
+    # a Python float keeps it fp32 (nerf/show_nerf.py:16)
+    f64 = isinstance(focal, np.floating) and np.dtype(type(focal)) == np.float64
+    rays = torch.empty((n, 2, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.mi_gen_rays(int(width), int(height), float(focal),
+                                   c2w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(ray0), int(n),
+                                   _lib.ptr(rays), int(f64), _lib.stream_ptr(device)), "mi_gen_rays")
+    return rays
+
+
+def sample_coarse(n: int, near: float, far: float, n_coarse: int, device, t_rand=None, seed: int = 0,
+                  exact_linspace: bool = True) -> torch.Tensor:
+    """Stratified depths z[n,Nc] (render.py:123-132).  t_rand[n,Nc] injects the jitter; otherwise an
+    in-kernel Philox stream keyed by ``seed`` is used."""
+    lib = _lib.load()
+    z = torch.empty((n, n_coarse), dtype=torch.float32, device=device)
+    if t_rand is not None:
+        t_rand = _f32c(t_rand, device)
+        if tuple(t_rand.shape) != (n, n_coarse):
+            raise _lib.MiRenderError(f"t_rand must be [{n},{n_coarse}]")
+    zl = linspace_table(near, far, n_coarse, device) if exact_linspace else None
+    with torch.cuda.device(device):
+        _lib.check(lib.mi_sample_coarse(n, float(near), float(far), n_coarse, _lib.ptr(zl), _lib.ptr(t_rand),
+                                        int(seed) & (2 ** 64 - 1), _lib.ptr(z), _lib.stream_ptr(device)),
+                   "mi_sample_coarse")
+    return z
+
+
+def composite(raw: torch.Tensor, z: torch.Tensor, rays: torch.Tensor, want_weights: bool = True):
+    """raw_to_outputs (render.py:78-103): returns rgb[n,3], depth[n], acc[n], weights[n,S]|None."""
+    lib = _lib.load()
+    dev = raw.device
+    n, s = z.shape
+    raw, z, rays = _f32c(raw, dev), _f32c(z, dev), _f32c(rays, dev)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    w = torch.empty((n, s), dtype=torch.float32, device=dev) if want_weights else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_composite(n, s, _lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays), _lib.ptr(rgb), _lib.ptr(depth),
+                                    _lib.ptr(acc), _lib.ptr(w), _lib.stream_ptr(dev)), "mi_composite")
+    return rgb, depth, acc, w
+
+
+def sample_fine(z_coarse: torch.Tensor, weights: torch.Tensor, near: float, far: float, n_fine: int,
+                want_samples: bool = False, exact_linspace: bool = True):
+    """sample_pdf(mids, weights[...,1:-1], Nf) + detach + sort(cat) (render.py:140-142).
+    Returns z_fine[n,Nc+Nf] (and z_samples[n,Nf] when asked)."""
+    lib = _lib.load()
+    dev = z_coarse.device
+    n, nc = z_coarse.shape
+    z_coarse, weights = _f32c(z_coarse, dev), _f32c(weights, dev)
+    z_fine = torch.empty((n, nc + n_fine), dtype=torch.float32, device=dev)
+    zs = torch.empty((n, n_fine), dtype=torch.float32, device=dev) if want_samples else None
+    zl = linspace_table(near, far, nc, dev) if exact_linspace else None
+    ul = linspace_table(0.0, 1.0, n_fine, dev) if exact_linspace else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_sample_fine(n, float(near), float(far), nc, n_fine, _lib.ptr(zl), _lib.ptr(ul),
+                                      _lib.ptr(z_coarse), _lib.ptr(weights), _lib.ptr(zs), _lib.ptr(z_fine),
+                                      _lib.stream_ptr(dev)), "mi_sample_fine")
+    return (z_fine, zs) if want_samples else z_fine
+
+
+def _film_for(pf: PackedField, film, n_rays):
+    if not is_film(pf.kind):
+        return None, 1, n_rays
+    if film is None:
+        raise ValueError
+    film = _f32c(film, pf.device).reshape(-1, 9, 512)
+    groups = film.shape[0]
+    if n_rays % groups:
+        raise _lib.MiRenderError("rays must split evenly over the FiLM groups (images)")
+    return film, groups, n_rays // groups
+
+
+def field_eval_rays(pf: PackedField, rays: torch.Tensor, z: torch.Tensor, film=None) -> torch.Tensor:
+    """run_network on points o + d*z with view dirs d/|d| (render.py:122,134-135), fused.  raw[n,S,4]."""
+    lib = _lib.load()
+    dev = pf.device
+    rays, z = _f32c(rays, dev), _f32c(z, dev)
+    n, s = z.shape
+    film, groups, rpg = _film_for(pf, film, n)
+    raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_field_eval_rays(pf.kind, _lib.ptr(pf.refresh()), _lib.ptr(film), _lib.ptr(rays), _lib.ptr(z),
+                                          groups, rpg, s, _lib.ptr(raw), _lib.stream_ptr(dev)), "mi_field_eval_rays")
+    return raw
+
+
+class _Workspace:
+    """Grow-only per-device scratch for mi_render_rays (no allocation inside the library)."""
+    bufs: dict = {}
+
+    @classmethod
+    def get(cls, device, nbytes):
+        key = str(device)
+        b = cls.bufs.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+            cls.bufs[key] = b
+        return b
+
+
+def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, near: float, far: float,
+                      n_coarse: int, n_fine: int, film=None, t_rand=None, seed: int = 0, exact_linspace: bool = True):
+    """render_rays (render.py:106-147) as one C-ABI call: six launches on the current stream.
+    Returns the reference's 6-tuple."""
+    lib = _lib.load()
+    dev = pf_c.device
+    rays = _f32c(rays, dev).reshape(-1, 2, 3)
+    n = rays.shape[0]
+    film, groups, rpg = _film_for(pf_c, film, n) if is_film(pf_c.kind) else _film_for(pf_f, film, n)
+    if t_rand is not None:
+        t_rand = _f32c(t_rand, dev)
+        if tuple(t_rand.shape) != (n, n_coarse):
+            raise _lib.MiRenderError(f"t_rand must be [{n},{n_coarse}]")
+    outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ((n, 3), (n,), (n,), (n, 3), (n,), (n,))]
+    ws = _Workspace.get(dev, lib.mi_render_workspace_bytes(n, n_coarse, n_fine))
+    zl = linspace_table(near, far, n_coarse, dev) if exact_linspace else None
+    ul = linspace_table(0.0, 1.0, n_fine, dev) if exact_linspace else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_render_rays(pf_c.kind, _lib.ptr(pf_c.refresh()), pf_f.kind, _lib.ptr(pf_f.refresh()),
+                                      _lib.ptr(film), _lib.ptr(rays), groups, rpg, float(near), float(far),
+                                      n_coarse, n_fine, _lib.ptr(zl), _lib.ptr(ul), _lib.ptr(t_rand),
+                                      int(seed) & (2 ** 64 - 1), *[_lib.ptr(o) for o in outs], _lib.ptr(ws),
+                                      _lib.stream_ptr(dev)), "mi_render_rays")
+    return tuple(outs)

@@ -1,0 +1,177 @@
+"""The reference's `render` call surface on the HIP path.
+
+Mirrors, name for name and argument for argument, nerf/render.py (get_rays :7, sample_pdf :27,
+run_network :59, raw_to_outputs :78, render_rays :106, render_image :150, render_video :170) and the
+pi_GAN variants (pi_GAN/render.py:195-241).  Differences that do not change results:
+
+* device comes from the inputs / the model, not from the global default tensor type;
+* `render_rays` takes optional keyword-only `t_rand` / `seed` (the reference draws the jitter from
+  the global RNG, render.py:131, which cannot be matched across devices);
+* whole images are rendered in one launch sequence per (up to) 2^20 rays instead of 16 384-ray
+  chunks with a device->host sync each (render.py:158-163); `chunk` is accepted and ignored
+  unless smaller memory is needed.
+
+Known field models (fields.py) run the fused MLP; any other callable `network([M,6]) -> [M,4]`
+is driven through the same sampling / compositing kernels (generic path).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from tqdm import tqdm
+
+from . import _lib, fields, ops
+
+to8b = lambda x: (255 * np.clip(x, 0, 1)).astype(np.uint8)  # noqa: E731  (nerf/render.py:5)
+
+MAX_RAYS_PER_LAUNCH = 1 << 20
+
+
+def _device_of(*models, rays=None):
+    for m in models:
+        pf = fields.as_packed_field(m) if isinstance(m, torch.nn.Module) else None
+        if pf is not None:
+            return pf.device
+        if isinstance(m, torch.nn.Module):
+            for p in m.parameters():
+                if p.is_cuda:
+                    return p.device
+    if isinstance(rays, torch.Tensor) and rays.is_cuda:
+        return rays.device
+    if not torch.cuda.is_available():
+        raise _lib.MiRenderError("no ROCm device: the renderer has no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _fresh_seed() -> int:
+    # one draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def get_rays(width, height, focal, c2w):
+    """nerf/render.py:7-23.  Returns NumPy (rays_o, rays_d) [H,W,3] fp32 like the reference; the
+    arithmetic runs in the HIP ray generator (bit-identical to the NumPy expression)."""
+    dev = _device_of()
+    rays = ops.gen_rays(width, height, focal, c2w, dev).cpu().numpy().reshape(height, width, 2, 3)
+    return np.ascontiguousarray(rays[:, :, 0]), np.ascontiguousarray(rays[:, :, 1])
+
+
+def sample_pdf(bins, weights, N_samples):
+    """nerf/render.py:27-56 is only ever called as sample_pdf(mids, weights[...,1:-1], Nf) (render.py:140);
+    the kernel implements that call.  Exposed for star-import compatibility."""
+    raise _lib.MiRenderError("sample_pdf is fused into mirender.ops.sample_fine (takes z_coarse and weights)")
+
+
+def run_network(ray_samples, view_dirs, network, chunk=1024 * 64):
+    """nerf/render.py:59-75: flatten, append per-ray view dirs, evaluate `network`."""
+    n, s = ray_samples.shape[0], ray_samples.shape[1]
+    x = torch.cat([ray_samples.reshape(-1, 3), view_dirs[:, None].expand(n, s, 3).reshape(-1, 3)], -1)
+    pf = fields.as_packed_field(network)
+    if pf is not None and not fields.is_film(pf.kind):
+        out = fields.eval_points(pf, x)
+    else:
+        out = torch.cat([network(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)])
+    return out.reshape(n, s, 4)
+
+
+def raw_to_outputs(raw, z_vals, rays_d):
+    """nerf/render.py:78-103 on the compositing kernel: (rgb, depth, acc, weights)."""
+    rays = torch.stack([torch.zeros_like(rays_d), rays_d], 1)
+    return ops.composite(raw, z_vals, rays, want_weights=True)
+
+
+def _generic_field(network, rays, z, chunk=1024 * 64):
+    """Unknown callable: points/view dirs are formed with torch ops on the device and fed to it."""
+    o, d = rays[:, 0], rays[:, 1]
+    view = d / torch.norm(d, dim=-1, keepdim=True)
+    pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
+    return run_network(pts, view, network, chunk).to(torch.float32).contiguous()
+
+
+def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fine_sample_num, *,
+                t_rand=None, seed=None):
+    """nerf/render.py:106-147.  rays [N,2,3] -> (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f)."""
+    dev = _device_of(coarse_model, fine_model, rays=rays)
+    rays = torch.as_tensor(rays).to(device=dev, dtype=torch.float32).reshape(-1, 2, 3).contiguous()
+    nc, nf = int(coarse_sample_num), int(fine_sample_num)
+    if seed is None and t_rand is None:
+        seed = _fresh_seed()
+    pf_c, pf_f = fields.as_packed_field(coarse_model), fields.as_packed_field(fine_model)
+    if pf_c is not None and pf_f is not None:
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in pf_c.params + pf_f.params)
+        film = None
+        if fields.is_film(pf_c.kind) or fields.is_film(pf_f.kind):
+            film = fields.film_table(coarse_model if fields.is_film(pf_c.kind) else fine_model)
+            needs_grad = needs_grad or (torch.is_grad_enabled() and film.requires_grad)
+        if needs_grad:
+            from . import autograd
+            return autograd.render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0)
+        return ops.render_rays_fused(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0)
+
+    # generic path: sampling / compositing kernels around an arbitrary callable
+    n = rays.shape[0]
+    z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed or 0)
+    raw_c = ops.field_eval_rays(pf_c, rays, z_c) if pf_c is not None and not fields.is_film(pf_c.kind) \
+        else _generic_field(coarse_model, rays, z_c)
+    rgb_c, depth_c, acc_c, w_c = ops.composite(raw_c, z_c, rays)
+    z_f = ops.sample_fine(z_c, w_c, near, far, nf)
+    raw_f = ops.field_eval_rays(pf_f, rays, z_f) if pf_f is not None and not fields.is_film(pf_f.kind) \
+        else _generic_field(fine_model, rays, z_f)
+    rgb_f, depth_f, acc_f, _ = ops.composite(raw_f, z_f, rays, want_weights=False)
+    return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f
+
+
+def _render_image_device(width, height, focal, pose, near, far, coarse_model, fine_model, nc, nf, chunk,
+                         t_rand=None, seed=None, ray0=0, n_rays=None):
+    """Rays [ray0, ray0+n) of the image -> device tensors (rgb[n,3], depth[n], acc[n]) of the FINE pass."""
+    dev = _device_of(coarse_model, fine_model)
+    total = width * height
+    n_rays = total - ray0 if n_rays is None else n_rays
+    step = MAX_RAYS_PER_LAUNCH if not chunk else max(int(chunk), 2)
+    step = max(step, 16384)
+    if seed is None and t_rand is None:
+        seed = _fresh_seed()
+    parts = []
+    for i in range(ray0, ray0 + n_rays, step):
+        m = min(step, ray0 + n_rays - i)
+        rays = ops.gen_rays(width, height, focal, pose, dev, i, m)
+        tr = None if t_rand is None else t_rand[i:i + m]
+        out = render_rays(rays, near, far, coarse_model, fine_model, nc, nf, t_rand=tr,
+                          seed=None if seed is None else seed + i)
+        parts.append(out[3:6])
+    if len(parts) == 1:
+        return parts[0]
+    return tuple(torch.cat([p[k] for p in parts]) for k in range(3))
+
+
+def render_image(width, height, focal, pose, near, far, coarse_model, fine_model, coarse_sample_num,
+                 fine_sample_num, chunk=1024 * 16, *, t_rand=None, seed=None):
+    """nerf/render.py:150-167: NumPy rgb[H,W,3], depth[H,W,1], acc[H,W,1] of the fine pass."""
+    with torch.no_grad():
+        rgb, depth, acc = _render_image_device(width, height, focal, pose, near, far, coarse_model, fine_model,
+                                               int(coarse_sample_num), int(fine_sample_num), None, t_rand, seed)
+    return (rgb.cpu().numpy().reshape(height, width, 3), depth.cpu().numpy().reshape(height, width, 1),
+            acc.cpu().numpy().reshape(height, width, 1))
+
+
+render_image_np = render_image   # pi_GAN/render.py:209-226 is the same function
+
+
+def render_image_tensor(width, height, focal, pose, near, far, coarse_model, fine_model, coarse_sample_num,
+                        fine_sample_num, chunk=1024 * 16, *, t_rand=None, seed=None):
+    """pi_GAN/render.py:195-206: rgb of the fine pass as a device tensor [H,W,3] carrying the autograd graph."""
+    rgb, _, _ = _render_image_device(width, height, focal, pose, near, far, coarse_model, fine_model,
+                                     int(coarse_sample_num), int(fine_sample_num), None, t_rand, seed)
+    return rgb.reshape(height, width, 3)
+
+
+def render_video(width, height, focal, poses, near, far, coarse_model, fine_model, coarse_sample_num,
+                 fine_sample_num, chunk=1024 * 16):
+    """nerf/render.py:170-182 (and the evident intent of pi_GAN/render.py:229-241, whose body unpacks
+    three values from the tensor-returning render_image): stacked NumPy frames."""
+    frames = [render_image(width, height, focal, p, near, far, coarse_model, fine_model, coarse_sample_num,
+                           fine_sample_num, chunk) for p in tqdm(poses)]
+    return tuple(np.stack([f[k] for f in frames]) for k in range(3))
+
+
+render_video_np = render_video

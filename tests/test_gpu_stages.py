@@ -1,0 +1,309 @@
+"""GPU parity, stage by stage, through the C ABI (mirender.ops -> ctypes -> libmirender.so).
+
+Each HIP stage is fed the ORACLE's inputs for that stage (injected intermediates)
+and compared with the committed golden fixtures and with the oracle on fresh seeded inputs.
+Tolerance: 1e-4 absolute (BASELINE.json north_star) unless a tighter one is stated; bit-exact
+where the stage is pure fp32 arithmetic in a fixed order (rays, stratified depths).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fields as ofields, render_ref as R, synth  # noqa: E402
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mi():
+    from mirender import _lib, fields, ops
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    _lib.load()
+    return type("MI", (), {"fields": fields, "ops": ops, "lib": _lib})
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def to_dev(a):
+    return torch.as_tensor(np.asarray(a)).to(dev())
+
+
+def maxerr(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if a.size else 0.0
+
+
+def packed(mi, kind_name, sd):
+    kind = {v: k for k, v in mi.fields.KIND_NAMES.items()}[kind_name]
+    params = []
+    for key, _ in mi.fields.SPECS[kind]:
+        params += [sd[key + ".weight"].to(dev()), sd[key + ".bias"].to(dev())]
+    return mi.fields.PackedField(kind, params)
+
+
+# ------------------------------------------------------------------ rays
+def test_gen_rays_golden_bit_exact(mi, golden):
+    g = golden("rays_f1")
+    W, H = int(g["W"]), int(g["H"])
+    rays = mi.ops.gen_rays(W, H, float(g["focal"]), g["pose_nerf"], dev()).cpu().numpy().reshape(H, W, 2, 3)
+    assert np.array_equal(rays[:, :, 0], g["rays_o"]) and np.array_equal(rays[:, :, 1], g["rays_d"])
+    rays = mi.ops.gen_rays(W, H, float(g["focal_pigan"]), g["pose_pigan"], dev()).cpu().numpy().reshape(H, W, 2, 3)
+    assert np.array_equal(rays[:, :, 1], g["rays_d_pigan"])
+
+
+@pytest.mark.parametrize("W,H", [(100, 100), (400, 400), (800, 800), (37, 19)])
+def test_gen_rays_vs_oracle(mi, W, H):
+    pose = synth.pose_degrees(4.0, 63.0, -30.0)
+    focal = 1.3875 * W
+    ref = R.rays_from_camera(W, H, focal, pose)
+    got = mi.ops.gen_rays(W, H, focal, pose, dev()).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # sub-range of the ray list (multi-GPU shards)
+    got = mi.ops.gen_rays(W, H, focal, pose, dev(), ray0=W * H // 3, n=W * H // 2).cpu().numpy()
+    assert np.array_equal(got, ref[W * H // 3: W * H // 3 + W * H // 2])
+
+
+def test_gen_rays_float64_focal(mi):
+    # pi_GAN/modules.py:127: focal is an np.float64 scalar -> NumPy computes in fp64, torch.tensor rounds to fp32
+    W = H = 128
+    focal = W / 2 / np.tan(12 / 2 * np.pi / 180)
+    assert isinstance(focal, np.floating)
+    pose = synth.pose_radians(1.0, 0.2, -0.1)
+    o, d = R.get_rays(W, H, focal, pose)
+    assert d.dtype == np.float64
+    ref = np.stack([np.broadcast_to(o, d.shape), d], 2).reshape(-1, 2, 3).astype(np.float32)
+    got = mi.ops.gen_rays(W, H, focal, pose, dev()).cpu().numpy()
+    assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------ stratified depths
+@pytest.mark.parametrize("near,far,nc", [(2.0, 6.0, 64), (2.0, 6.0, 32), (0.5, 1.5, 12), (0.5, 1.5, 24), (0.1, 1.9, 7)])
+def test_sample_coarse_bit_exact(mi, near, far, nc):
+    n = 513
+    tr = synth.t_rand(n, nc, seed=nc)
+    ref, _ = R.stratified_z(n, near, far, nc, tr)
+    got = mi.ops.sample_coarse(n, near, far, nc, dev(), to_dev(tr))
+    assert np.array_equal(got.cpu().numpy(), ref.numpy())
+    # in-kernel linspace (ATen scalar formula) stays within 1 ulp of the CPU table
+    got2 = mi.ops.sample_coarse(n, near, far, nc, dev(), to_dev(tr), exact_linspace=False)
+    assert maxerr(got2, ref) <= 5e-7
+
+
+def test_sample_coarse_philox(mi):
+    n, nc = 4096, 64
+    a = mi.ops.sample_coarse(n, 2.0, 6.0, nc, dev(), None, seed=7)
+    b = mi.ops.sample_coarse(n, 2.0, 6.0, nc, dev(), None, seed=7)
+    c = mi.ops.sample_coarse(n, 2.0, 6.0, nc, dev(), None, seed=8)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    lin = torch.linspace(2.0, 6.0, nc)
+    mids = 0.5 * (lin[1:] + lin[:-1])
+    lo = torch.cat([lin[:1], mids]).to(dev())
+    hi = torch.cat([mids, lin[-1:]]).to(dev())
+    u = (a - lo) / (hi - lo)
+    assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 + 1e-6
+    assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 5e-3
+    assert bool((a[:, 1:] >= a[:, :-1]).all())
+
+
+# ------------------------------------------------------------------ compositing
+@pytest.mark.parametrize("name", ["composite_f2", "composite_f2_s36", "composite_f2_s192"])
+def test_composite_golden(mi, golden, name):
+    g = golden(name)
+    rays = np.stack([np.zeros_like(g["rays_d"]), g["rays_d"]], 1)
+    rgb, depth, acc, w = mi.ops.composite(to_dev(g["raw"]), to_dev(g["z"]), to_dev(rays))
+    assert maxerr(rgb, g["rgb"]) <= 2e-5
+    assert maxerr(acc, g["acc"]) <= 2e-5
+    assert maxerr(w, g["weights"]) <= 2e-5
+    assert maxerr(depth, g["depth"]) <= 1e-4
+
+
+@pytest.mark.parametrize("S", [1, 2, 12, 16, 17, 32, 33, 64, 100, 192, 256])
+def test_composite_vs_oracle_ragged(mi, S):
+    rng = np.random.Generator(np.random.PCG64(S))
+    n = 301
+    raw = rng.uniform(0, 1, size=(n, S, 4)).astype(np.float32)
+    raw[..., 3] = rng.exponential(2.0, size=(n, S)).astype(np.float32) * (rng.random((n, S)) < 0.4)
+    z = np.sort(rng.uniform(2, 6, size=(n, S)).astype(np.float32), -1)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    ref = R.composite(torch.from_numpy(raw), torch.from_numpy(z), torch.from_numpy(rd))
+    rays = np.stack([np.zeros_like(rd), rd], 1)
+    got = mi.ops.composite(to_dev(raw), to_dev(z), to_dev(rays))
+    for a, b, tol in zip(got, ref, (2e-5, 1e-4, 2e-5, 2e-5)):
+        assert maxerr(a, b) <= tol
+
+
+def test_composite_properties_full_size(mi):
+    # size-independent properties at C3 scale (640 000 rays would need 2 GB of raw; 200 000 x 192 here)
+    n, S = 200_000, 192
+    g = torch.Generator(device="cpu").manual_seed(0)
+    z = torch.sort(torch.rand((n, S), generator=g) * 4 + 2, -1).values.to(dev())
+    rays = torch.randn((n, 2, 3), generator=g).to(dev())
+    raw = torch.rand((n, S, 4), generator=g).to(dev())
+    raw[..., 3] *= 3.0
+    rgb, depth, acc, w = mi.ops.composite(raw, z, rays)
+    assert torch.isfinite(rgb).all() and float(acc.min()) >= 0 and float(acc.max()) <= 1 + 1e-5
+    assert maxerr(w.sum(-1), acc) <= 2e-5                     # acc is the sum of the weights
+    assert float((depth - (w * z).sum(-1)).abs().max()) <= 1e-4
+    # zero density -> white background, zero depth (render.py:101)
+    raw0 = raw.clone()
+    raw0[..., 3] = 0
+    rgb0, depth0, acc0, _ = mi.ops.composite(raw0, z, rays)
+    assert float((rgb0 - 1).abs().max()) == 0 and float(acc0.abs().max()) == 0 and float(depth0.abs().max()) == 0
+    # colour linearity: compositing a constant colour c gives c*acc + (1-acc)
+    rawc = raw.clone()
+    rawc[..., :3] = 0.25
+    rgbc, _, accc, _ = mi.ops.composite(rawc, z, rays)
+    assert float((rgbc - (0.25 * accc + (1 - accc))[:, None]).abs().max()) <= 2e-5
+
+
+# ------------------------------------------------------------------ hierarchical sampling
+def _fine_stats(got, ref):
+    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    return float(d.max()), float((d > TOL).mean())
+
+
+def test_sample_fine_golden_pdf(mi, golden):
+    """sample_pdf edge cases of F3 pushed through the render_rays call shape: bins must be the mids of a
+    linspace, so this test rebuilds weights from the fixture and compares with the oracle's sample_pdf."""
+    near, far, nc = 2.0, 6.0, 64
+    g = golden("pdf_f3")
+    w_in = g["weights"]                                   # [10, 62] = interior weights
+    n = w_in.shape[0]
+    w_full = np.zeros((n, nc), np.float32)
+    w_full[:, 1:-1] = w_in
+    zc, mids = R.stratified_z(n, near, far, nc, synth.t_rand(n, nc, 5))
+    for nf in (0, 1, 24, 128):
+        ref_s = R.sample_pdf(mids, torch.from_numpy(w_in), nf)
+        ref_f = torch.sort(torch.cat([zc, ref_s], -1), -1).values
+        zf, zs = mi.ops.sample_fine(to_dev(zc), to_dev(w_full), near, far, nf, want_samples=True)
+        assert tuple(zf.shape) == (n, nc + nf)
+        assert maxerr(zs, ref_s) <= 1e-5
+        assert maxerr(zf, ref_f) <= 1e-5
+
+
+@pytest.mark.parametrize("name,nc,nf,near,far", [
+    ("render_f5_nerf_64_128_sharp", 64, 128, 2.0, 6.0), ("render_f5_nerf_64_128", 64, 128, 2.0, 6.0),
+    ("render_f5_siren_nerf_64_128", 64, 128, 2.0, 6.0), ("render_f5_film_siren_nerf_12_24", 12, 24, 0.5, 1.5),
+    ("render_f5_nerf_32_0_sharp", 32, 0, 2.0, 6.0)])
+def test_sample_fine_golden_render(mi, golden, name, nc, nf, near, far):
+    g = golden(name)
+    zf, zs = mi.ops.sample_fine(to_dev(g["z_coarse"]), to_dev(g["weights_c"]), near, far, nf, want_samples=True)
+    mx, frac = _fine_stats(zs.cpu().numpy(), g["z_samples"])
+    # the denom<1e-5 guard (render.py:52) makes a handful of samples discontinuous in the cdf's last bits
+    assert frac <= 0.002, (mx, frac)
+    mx, frac = _fine_stats(zf.cpu().numpy(), g["z_fine"])
+    assert frac <= 0.004, (mx, frac)
+    assert bool((zf[:, 1:] >= zf[:, :-1]).all())
+
+
+def test_sample_fine_is_sorted_permutation(mi):
+    n, nc, nf = 20_000, 64, 128
+    tr = synth.t_rand(n, nc, 3)
+    zc, _ = R.stratified_z(n, 2.0, 6.0, nc, tr)
+    w = torch.rand((n, nc), generator=torch.Generator().manual_seed(1)) ** 6
+    zf, zs = mi.ops.sample_fine(to_dev(zc), to_dev(w), 2.0, 6.0, nf, want_samples=True)
+    assert bool((zf[:, 1:] >= zf[:, :-1]).all())
+    ref = torch.sort(torch.cat([zc.to(dev()), zs], -1), -1).values
+    assert torch.equal(zf, ref)                            # the merge is an exact sort of the same multiset
+
+
+# ------------------------------------------------------------------ fused field MLP
+KINDS = ["nerf", "siren_nerf", "film_siren_nerf", "film_siren_nerf_nodir"]
+
+
+def _field_err(out, ref):
+    out, ref = out.cpu().numpy().astype(np.float64), np.asarray(ref, np.float64)
+    e_rgb = np.abs(out[:, :3] - ref[:, :3]).max()
+    e_sig = (np.abs(out[:, 3] - ref[:, 3]) / np.maximum(1.0, np.abs(ref[:, 3]))).max()
+    return float(e_rgb), float(e_sig)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("sharp", [False, True])
+def test_field_golden(mi, golden, kind, sharp):
+    g = golden("field_f4")
+    tag = f"{kind}{'_sharp' if sharp else ''}"
+    sd = synth.state_dict(kind, seed=10, sharp=sharp, bias_jitter=0.05)
+    assert synth.digest(sd) == str(g[f"digest.{tag}"])
+    pf = packed(mi, kind, sd)
+    film = to_dev(g["film"][1:2]) if kind.startswith("film") else None
+    out = mi.fields.eval_points(pf, to_dev(g["x"]), film)
+    e_rgb, e_sig = _field_err(out, g[f"out.{tag}"])
+    assert e_rgb <= TOL and e_sig <= TOL, (e_rgb, e_sig)
+
+
+@pytest.mark.parametrize("kind", KINDS + ["tiny_nerf"])
+@pytest.mark.parametrize("m", [1, 31, 128, 129, 1000])
+def test_field_vs_oracle_ragged(mi, kind, m):
+    sd = synth.state_dict(kind, seed=77, sharp=True, bias_jitter=0.05)
+    rng = np.random.Generator(np.random.PCG64(m))
+    x = rng.uniform(-2, 2, size=(m, 6)).astype(np.float32)
+    film = synth.film_params(1, seed=9)
+    with torch.no_grad():
+        ref = ofields.make_field(kind, sd, film[0])(torch.from_numpy(x))
+    out = mi.fields.eval_points(packed(mi, kind, sd), to_dev(x), to_dev(film) if kind.startswith("film") else None)
+    e_rgb, e_sig = _field_err(out, ref.numpy())
+    assert e_rgb <= TOL and e_sig <= TOL, (e_rgb, e_sig)
+
+
+def test_field_film_groups(mi):
+    """Batched FiLM tables: group g of the points uses film[g]."""
+    kind, b, ppg = "film_siren_nerf", 3, 200
+    sd = synth.state_dict(kind, seed=5, sharp=True)
+    film = synth.film_params(b, seed=2)
+    x = np.random.Generator(np.random.PCG64(0)).uniform(-1, 1, size=(b * ppg, 6)).astype(np.float32)
+    out = mi.fields.eval_points(packed(mi, kind, sd), to_dev(x), to_dev(film)).cpu().numpy()
+    with torch.no_grad():
+        for i in range(b):
+            ref = ofields.make_field(kind, sd, film[i])(torch.from_numpy(x[i * ppg:(i + 1) * ppg])).numpy()
+            e_rgb, e_sig = _field_err(torch.from_numpy(out[i * ppg:(i + 1) * ppg]), ref)
+            assert e_rgb <= TOL and e_sig <= TOL
+
+
+def test_field_repack_after_inplace_update(mi):
+    sd = synth.state_dict("nerf", seed=1, sharp=True)
+    pf = packed(mi, "nerf", sd)
+    x = to_dev(np.random.Generator(np.random.PCG64(1)).uniform(-1, 1, size=(64, 6)).astype(np.float32))
+    a = mi.fields.eval_points(pf, x)
+    with torch.no_grad():
+        pf.params[0].mul_(1.5)          # optimiser-style in-place update bumps the version counter
+    b = mi.fields.eval_points(pf, x)
+    assert not torch.equal(a, b)
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    sd2["layers_pos.0.weight"] *= 1.5
+    with torch.no_grad():
+        ref = ofields.make_field("nerf", sd2)(x.cpu())
+    assert _field_err(b, ref.numpy())[0] <= TOL
+
+
+# ------------------------------------------------------------------ run_network fused with point generation
+@pytest.mark.parametrize("name,kind", [("render_f5_nerf_64_128_sharp", "nerf"), ("render_f5_siren_nerf_64_128", "siren_nerf"),
+                                       ("render_f5_film_siren_nerf_12_24", "film_siren_nerf"),
+                                       ("render_f5_film_siren_nerf_nodir_12_24", "film_siren_nerf_nodir")])
+def test_field_eval_rays_golden(mi, golden, name, kind):
+    g = golden(name)
+    if kind.startswith("film"):
+        sd_c = sd_f = synth.state_dict(kind, seed=30, sharp=True)
+        film = to_dev(g["film"][None])
+    else:
+        sharp = name.endswith("sharp")
+        sd_c = synth.state_dict(kind, seed=20, sharp=sharp, bias_jitter=0.05)
+        sd_f = synth.state_dict(kind, seed=21, sharp=sharp, bias_jitter=0.05)
+        film = None
+    rays = to_dev(g["rays"])
+    for sd, zk, rk in ((sd_c, "z_coarse", "raw_c"), (sd_f, "z_fine", "raw_f")):
+        raw = mi.ops.field_eval_rays(packed(mi, kind, sd), rays, to_dev(g[zk]), film)
+        ref = g[rk].reshape(-1, 4)
+        e_rgb, e_sig = _field_err(raw.reshape(-1, 4), ref)
+        assert e_rgb <= TOL and e_sig <= TOL, (zk, e_rgb, e_sig)
+        # composite of the HIP raw against the fixture's outputs for this pass (injected z)
+        rgb, depth, acc, w = mi.ops.composite(raw, to_dev(g[zk]), rays)
+        sfx = "c" if zk == "z_coarse" else "f"
+        assert maxerr(rgb, g["rgb_" + sfx]) <= TOL and maxerr(acc, g["acc_" + sfx]) <= TOL
+        assert maxerr(depth, g["depth_" + sfx]) <= 5e-4      # depth is scaled by z in [2,6]
