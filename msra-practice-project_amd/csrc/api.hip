@@ -159,6 +159,18 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
     if ((rc = mi_field_eval_rays(kind_coarse, packed_coarse, film, rays, z_c, n_groups, rays_per_group, n_coarse, raw_c,
                                  stream))) return rc;
     if ((rc = mi_composite(n, n_coarse, raw_c, z_c, rays, rgb_c, depth_c, acc_c, w_c, stream))) return rc;
+    if (n_fine == 0 && kind_fine == kind_coarse && packed_fine == packed_coarse) {
+        // render.py:140-145 with Nf = 0 and one model: sort(z_coarse) == z_coarse, so the second pass would
+        // re-evaluate identical inputs; alias its outputs instead.
+        hipStream_t s = (hipStream_t)stream;
+        if (hipMemcpyAsync(rgb_f, rgb_c, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(depth_f, depth_c, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(acc_f, acc_c, n * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            set_error("mi_render_rays: output alias copy failed");
+            return MI_EHIP;
+        }
+        return MI_OK;
+    }
     if ((rc = mi_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_c, w_c, nullptr, z_f, stream))) return rc;
     if ((rc = mi_field_eval_rays(kind_fine, packed_fine, film, rays, z_f, n_groups, rays_per_group, S, raw_f, stream)))
         return rc;

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(256) void composite_kernel(int64_t n, int S, const 
     const int64_t rc = live ? ray : n - 1;
     const float* rd = rays + rc * 6 + 3;
     const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
-    float T = 1.f, sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    double T = 1.0;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
     for (int k0 = 0; k0 < S; k0 += G) {
         const int k = k0 + sub;
         const bool in = k < S;
@@ -114,16 +115,17 @@ __global__ __launch_bounds__(256) void composite_kernel(int64_t n, int S, const 
         delta = delta * nrm;
         const float alpha = in ? 1.0f - expf(-c.w * delta) : 0.f;
         const float f = in ? (1.0f - alpha) + 1e-10f : 1.f;
-        // inclusive product scan inside the G-lane group
-        float p = f;
+        // inclusive product scan inside the G-lane group.  The running product is kept in fp64 and
+        // rounded to fp32 per sample, as ATen's CPU cumprod does (accumulate type of float is double).
+        double p = (double)f;
 #pragma unroll
         for (int o = 1; o < G; o <<= 1) {
-            const float q = __shfl_up(p, o, G);
+            const double q = __shfl_up(p, o, G);
             if (sub >= o) p *= q;
         }
-        float excl = __shfl_up(p, 1, G);
-        if (sub == 0) excl = 1.f;
-        const float w = alpha * (T * excl);
+        double excl = __shfl_up(p, 1, G);
+        if (sub == 0) excl = 1.0;
+        const float w = alpha * (float)(T * excl);
         T = T * __shfl(p, G - 1, G);
         if (in) {
             sr += w * c.x; sg += w * c.y; sb += w * c.z; sd += w * zk; sa += w;
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(256) void composite_kernel(int64_t n, int S, const 
 
 // ---------------------------------------------------------------------------------------
 // sample_fine: one wave per ray.  bins = mids of the coarse linspace, w = weights[1:-1]+1e-5,
-// pdf = w/sum(w), cdf = [0, cumsum(pdf)] accumulated SEQUENTIALLY per entry like torch.cumsum
-// on CPU; u = linspace(0,1,Nf); idx = #(cdf <= u) (searchsorted right=True); guarded lerp;
+// pdf = w/sum(w), cdf = [0, cumsum(pdf)] with the running sum in fp64 rounded per entry like
+// torch.cumsum on CPU; u = linspace(0,1,Nf); idx = #(cdf <= u) (searchsorted right=True); guarded lerp;
 // then z_fine = sort(cat(z_coarse, z_samples)) by full rank counting (no sortedness assumed).
 // LDS per wave: cdf[Nc] | bins[Nc] | zall[Nc+Nf]
 // ---------------------------------------------------------------------------------------
@@ -181,10 +183,12 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
         for (int j = lane; j < nw; j += 64) zall[j] = (wr[j + 1] + 1e-5f) / total;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ATen's CPU cumsum keeps the running sum in the accumulate type of float, i.e. DOUBLE, and rounds
+        // every output to fp32 (cpu_cum_base_kernel): do the same so the cdf matches bit for bit.
         for (int j = lane; j < nb; j += 64) {
-            float s = 0.f;
-            for (int i = 0; i < j; ++i) s = i == 0 ? zall[0] : s + zall[i];
-            cdf[j] = s;
+            double s = 0.0;
+            for (int i = 0; i < j; ++i) s += (double)zall[i];
+            cdf[j] = (float)s;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

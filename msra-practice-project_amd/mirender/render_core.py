@@ -135,7 +135,7 @@ def _render_image_device(width, height, focal, pose, near, far, coarse_model, fi
     for i in range(ray0, ray0 + n_rays, step):
         m = min(step, ray0 + n_rays - i)
         rays = ops.gen_rays(width, height, focal, pose, dev, i, m)
-        tr = None if t_rand is None else t_rand[i:i + m]
+        tr = None if t_rand is None else t_rand[i - ray0:i - ray0 + m]   # row k of t_rand <-> ray ray0 + k
         out = render_rays(rays, near, far, coarse_model, fine_model, nc, nf, t_rand=tr,
                           seed=None if seed is None else seed + i)
         parts.append(out[3:6])

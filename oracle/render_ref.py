@@ -40,7 +40,7 @@ def rays_from_camera(width, height, focal, c2w) -> np.ndarray:
 
 def stratified_z(n_rays: int, near: float, far: float, n_coarse: int, t_rand: torch.Tensor):
     """render.py:123-132.  Returns (z_vals[N,Nc], mids[N,Nc-1])."""
-    z = torch.linspace(near, far, steps=n_coarse).unsqueeze(0).expand(n_rays, n_coarse)
+    z = torch.linspace(near, far, steps=n_coarse, dtype=t_rand.dtype).unsqueeze(0).expand(n_rays, n_coarse)
     mids = 0.5 * (z[..., 1:] + z[..., :-1])
     hi = torch.cat([mids, z[..., -1:]], -1)
     lo = torch.cat([z[..., :1], mids], -1)
@@ -82,7 +82,7 @@ def sample_pdf(bins, weights, n_samples: int):
     pdf = w / torch.sum(w, -1, keepdim=True)
     cdf = torch.cumsum(pdf, -1)
     cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
-    u = torch.linspace(0.0, 1.0, steps=n_samples).expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
+    u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=cdf.dtype).expand(list(cdf.shape[:-1]) + [n_samples]).contiguous()
     idx = torch.searchsorted(cdf.detach(), u, right=True)
     lo = torch.clamp(idx - 1, min=0)
     hi = torch.clamp(idx, max=cdf.shape[-1] - 1)
@@ -148,6 +148,15 @@ def render_image(width, height, focal, pose, near, far, coarse_field, fine_field
     depth = torch.cat([p[1] for p in parts]).reshape(height, width, 1)
     acc = torch.cat([p[2] for p in parts]).reshape(height, width, 1)
     return rgb.numpy(), depth.numpy(), acc.numpy()
+
+
+def render_rays_f64(rays, near, far, coarse_field64, fine_field64, n_coarse, n_fine, t_rand,
+                    z_fine_override=None) -> RenderTrace:
+    """The same algorithm evaluated in fp64 (fields must hold fp64 weights).  Used by tests to measure
+    the fp32 CPU path's own distance from exact arithmetic: a stage whose fp32 oracle already deviates by
+    more than the 1e-4 gate from its fp64 self is judged against that floor, not against 1e-4."""
+    z_o = None if z_fine_override is None else z_fine_override.double()
+    return render_rays(rays.double(), near, far, coarse_field64, fine_field64, n_coarse, n_fine, t_rand.double(), z_o)
 
 
 def psnr(a, b) -> float:

