@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s of the ray-march + field-MLP + alpha-composite path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = one synthetic 800x800 frame (640 000 rays) rendered with 64 coarse + 128 fine samples per ray
+through separate coarse / fine NeRF 8x256 models (BASELINE.json config C3, nerf/configs/lego.json) by the
+product path render_image_dist -> mi_render_rays: six launches per frame, rays generated on the device,
+weights and rays resident in HBM before the timed region.  With N > 1 the frame's rays are split into N
+contiguous ranges (one process per GPU) and reassembled by one RCCL all-gather per frame, so total work
+is fixed: scaling = "strong".  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      fused field-MLP kernel (nerf_fwd_kernel) timed with HIP events around its launches inside
+                the timed region; achieved = algorithmic FLOPs (2 x 591 488 MACs per point)
+                per launch / mean launch duration, peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md)
+  frame64       the "800^2 frame @ 64 samples" figure of BASELINE.json's metric (Nc=64, Nf=0, one model)
+  cpu_baseline  the CPU oracle (oracle/render_ref.py, PyTorch CPU, all host cores) on a bounded sample of
+                the same workload, rank 0, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "msra-practice-project_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+W = H = 800
+NEAR, FAR = 2.0, 6.0            # nerf/configs/lego.json:10-11
+NC, NF = 64, 128
+
+
+def pose_degrees(radius, theta, phi):
+    """camera_pos_to_transform_matrix of nerf/data_loader.py:39-51 (degrees), restated."""
+    def rx(a):
+        c, s = np.cos(a), np.sin(a)
+        return np.array([[1, 0, 0, 0], [0, c, -s, 0], [0, s, c, 0], [0, 0, 0, 1]], dtype=np.float32)
+
+    def ry(a):
+        c, s = np.cos(a), np.sin(a)
+        return np.array([[c, 0, -s, 0], [0, 1, 0, 0], [s, 0, c, 0], [0, 0, 0, 1]], dtype=np.float32)
+    t = np.eye(4, dtype=np.float32)
+    t[2, 3] = radius
+    return ry(theta / 180.0 * np.pi) @ (rx(phi / 180.0 * np.pi) @ t)
+
+
+def make_models(dev):
+    from mirender import fields
+    torch.manual_seed(0)
+    coarse, fine = fields.NeRF().to(dev), fields.NeRF().to(dev)
+    with torch.no_grad():   # "sharp" variant of SURVEY.md §8d so the volume is not near-empty
+        for m in (coarse, fine):
+            m.output_layer_sigma.weight.mul_(50.0)
+            m.output_layer_sigma.bias.add_(5.0)
+    return coarse, fine
+
+
+class MlpTimer:
+    """HIP events around the coarse and fine field-MLP launches of mi_render_rays."""
+
+    def __init__(self, lib, n):
+        self.lib = lib
+        self.ev = [[lib.mi_event_create() for _ in range(4)] for _ in range(n)]
+        self.used = 0
+
+    def arm(self):
+        e = self.ev[self.used]
+        self.lib.mi_render_set_mlp_events(*e)
+        self.used += 1
+
+    def disarm(self):
+        self.lib.mi_render_set_mlp_events(None, None, None, None)
+
+    def times_ms(self):
+        import ctypes
+        out = []
+        ms = ctypes.c_float()
+        for e in self.ev[:self.used]:
+            row = []
+            for a, b in ((0, 1), (2, 3)):
+                self.lib.mi_event_elapsed_ms(e[a], e[b], ctypes.byref(ms))
+                row.append(ms.value)
+            out.append(row)
+        return out
+
+
+def usable_cpus() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host; oversubscribing a 16-core share with 100+ threads stalls)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(float(quota) / period)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(sample_rays=8192):
+    """Oracle (CPU restatement of the reference path) on a bounded sample of the C3 workload."""
+    from oracle import fields as ofields, render_ref as R, synth
+    torch.set_num_threads(usable_cpus())
+    sd_c = synth.state_dict("nerf", seed=0, sharp=True)
+    sd_f = synth.state_dict("nerf", seed=1, sharp=True)
+    fc, ff = ofields.make_field("nerf", sd_c), ofields.make_field("nerf", sd_f)
+    rays = R.rays_from_camera(W, H, 1.3875 * W, pose_degrees(4.0, 0.0, -30.0))
+    start = (H // 2) * W
+    rays = torch.from_numpy(rays[start:start + sample_rays])
+    tr = synth.t_rand(sample_rays, NC, seed=123)
+    with torch.no_grad():
+        R.render_rays(rays[:512], NEAR, FAR, fc, ff, NC, NF, tr[:512])      # warm-up
+        t0 = time.perf_counter()
+        R.render_rays(rays, NEAR, FAR, fc, ff, NC, NF, tr)
+        dt = time.perf_counter() - t0
+    return {"value": sample_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{sample_rays} rays of the 800x800 frame (rows from the image centre), Nc=64 Nf=128, "
+                      f"NeRF coarse+fine, torch CPU no_grad, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from mirender import _lib, dist as mdist, fields
+    lib = _lib.load()
+    coarse, fine = make_models(dev)
+    focal = 1.3875 * W                                       # nerf/show_nerf.py:16
+    thetas = np.linspace(-180, 180, 41)[:-1]                 # nerf/show_nerf.py:53 turntable
+    poses = [pose_degrees(4.0, float(t), -30.0) for t in thetas]
+    n_local = mdist.shard_range(W * H, rank, world)
+    n_local = n_local[1] - n_local[0]
+
+    def frame(i, nf=NF, fine_model=fine):
+        return mdist.render_image_dist(W, H, focal, poses[i % len(poses)], NEAR, FAR, coarse, fine_model, NC, nf,
+                                       seed=1000 + i)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        frame(i)
+    timer = MlpTimer(lib, args.steps)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        timer.arm()
+        out = frame(args.warmup + i)
+    timer.disarm()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out[0]).all())
+
+    # roofline of the dominant kernel, from the events recorded inside the timed region (this rank)
+    flops_pt = fields.FLOPS_PER_POINT[fields.NERF]
+    times = timer.times_ms()
+    launch_ms = [t for row in times for t in row]
+    launch_flops = [n_local * NC * flops_pt, n_local * (NC + NF) * flops_pt] * len(times)
+    mean_ms = sum(launch_ms) / len(launch_ms)
+    mean_flops = sum(launch_flops) / len(launch_flops)
+    achieved = mean_flops / (mean_ms * 1e-3) / 1e12
+    roofline = {"bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launches": len(launch_ms), "avg_launch_ms": mean_ms, "flops_per_launch": mean_flops,
+                "mlp_share_of_step": sum(launch_ms) / (elapsed * 1e3)}
+
+    # the "800^2 frame @ 64 samples" figure: Nc=64, Nf=0, fine model = coarse model (second pass aliased)
+    sync()
+    t1 = time.perf_counter()
+    reps = max(2, args.steps)
+    for i in range(reps):
+        frame(i, nf=0, fine_model=coarse)
+    sync()
+    f64_s = (time.perf_counter() - t1) / reps
+    if world > 1:
+        t = torch.tensor([f64_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        f64_s = float(t.item())
+
+    if rank == 0:
+        rays_per_s = W * H * args.steps / elapsed
+        line = {
+            "metric": "rays/sec (+ ms/800^2 frame @64 samples) at 1/2/4/8 MI355X; PSNR vs ref",
+            "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "nerf 800x800 frame, 64 coarse + 128 fine samples/ray, separate coarse/fine "
+                                   "NeRF 8x256 (BASELINE config C3), random-init weights (sigma head x50), "
+                                   "in-kernel Philox jitter, rays generated on device",
+                       "rays_per_step": W * H, "mlp_evals_per_ray": NC + NC + NF,
+                       "parallelism": f"ray-shard x{world} + RCCL all-gather" if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "frame64": {"ms_per_frame": f64_s * 1e3, "rays_per_s": W * H / f64_s,
+                        "workload": "800x800 frame, 64 samples/ray, one NeRF 8x256 (Nf=0)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+            line["gpu_over_cpu"] = rays_per_s / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

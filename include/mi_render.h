@@ -121,6 +121,19 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
                    const float* t_rand, uint64_t seed, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f,
                    void* workspace, void* stream);
 
+/* ---- measurement hooks (bench.py) ---------------------------------------------------- */
+
+/* HIP events owned by the library's HIP runtime (the one the kernels launch on), so a host
+ * program can time individual launches without linking HIP itself.  mi_event_elapsed_ms
+ * synchronises on `stop`. */
+void* mi_event_create(void);
+void mi_event_destroy(void* ev);
+int mi_event_record(void* ev, void* stream);
+int mi_event_elapsed_ms(void* start, void* stop, float* ms);
+/* While set (thread-local; pass NULLs to clear), mi_render_rays records these events on its
+ * stream immediately before/after the coarse and the fine field-MLP launch. */
+void mi_render_set_mlp_events(void* start_coarse, void* stop_coarse, void* start_fine, void* stop_fine);
+
 #ifdef __cplusplus
 }
 #endif

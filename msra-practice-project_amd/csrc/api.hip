@@ -11,6 +11,7 @@
 namespace mi {
 
 static thread_local char g_err[512] = "";
+static thread_local hipEvent_t g_mlp_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -156,8 +157,11 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
     float* raw_f = take(n * (int64_t)S * 4);
     int rc;
     if ((rc = mi_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, z_c, stream))) return rc;
+    hipStream_t hs = (hipStream_t)stream;
+    if (g_mlp_ev[0]) (void)hipEventRecord(g_mlp_ev[0], hs);
     if ((rc = mi_field_eval_rays(kind_coarse, packed_coarse, film, rays, z_c, n_groups, rays_per_group, n_coarse, raw_c,
                                  stream))) return rc;
+    if (g_mlp_ev[1]) (void)hipEventRecord(g_mlp_ev[1], hs);
     if ((rc = mi_composite(n, n_coarse, raw_c, z_c, rays, rgb_c, depth_c, acc_c, w_c, stream))) return rc;
     if (n_fine == 0 && kind_fine == kind_coarse && packed_fine == packed_coarse) {
         // render.py:140-145 with Nf = 0 and one model: sort(z_coarse) == z_coarse, so the second pass would
@@ -172,9 +176,34 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
         return MI_OK;
     }
     if ((rc = mi_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_c, w_c, nullptr, z_f, stream))) return rc;
+    if (g_mlp_ev[2]) (void)hipEventRecord(g_mlp_ev[2], hs);
     if ((rc = mi_field_eval_rays(kind_fine, packed_fine, film, rays, z_f, n_groups, rays_per_group, S, raw_f, stream)))
         return rc;
+    if (g_mlp_ev[3]) (void)hipEventRecord(g_mlp_ev[3], hs);
     return mi_composite(n, S, raw_f, z_f, rays, rgb_f, depth_f, acc_f, nullptr, stream);
+}
+
+void* mi_event_create(void) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }
+    return (void*)e;
+}
+void mi_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int mi_event_record(void* ev, void* stream) {
+    if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) { set_error("hipEventRecord failed"); return MI_EHIP; }
+    return MI_OK;
+}
+int mi_event_elapsed_ms(void* start, void* stop, float* ms) {
+    if (hipEventSynchronize((hipEvent_t)stop) != hipSuccess ||
+        hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) {
+        set_error("hipEventElapsedTime failed");
+        return MI_EHIP;
+    }
+    return MI_OK;
+}
+void mi_render_set_mlp_events(void* start_coarse, void* stop_coarse, void* start_fine, void* stop_fine) {
+    g_mlp_ev[0] = (hipEvent_t)start_coarse; g_mlp_ev[1] = (hipEvent_t)stop_coarse;
+    g_mlp_ev[2] = (hipEvent_t)start_fine; g_mlp_ev[3] = (hipEvent_t)stop_fine;
 }
 
 }  // extern "C"

@@ -40,6 +40,11 @@ SIGNATURES = {
     "mi_render_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
                               _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_event_create": (_vp, []),
+    "mi_event_destroy": (None, [_vp]),
+    "mi_event_record": (_int, [_vp, _vp]),
+    "mi_event_elapsed_ms": (_int, [_vp, _vp, ctypes.POINTER(_f32)]),
+    "mi_render_set_mlp_events": (None, [_vp, _vp, _vp, _vp]),
 }
 
 _lib = None
