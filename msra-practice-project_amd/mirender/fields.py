@@ -179,18 +179,23 @@ class _FusedField(torch.nn.Module):
         self.reset_parameters()
 
     def _register(self, key, w, b):
-        mod = self
-        for p in key.split("."):
-            if not hasattr(mod, p):
-                mod.add_module(p, torch.nn.Module())
-            mod = getattr(mod, p)
-        mod.weight, mod.bias = w, b
+        # "layers_pos.3" -> self.layers_pos (ModuleList, indexable like the reference's) [3]
+        leaf = torch.nn.Module()
+        leaf.weight, leaf.bias = w, b
+        parts = key.split(".")
+        if len(parts) == 1:
+            self.add_module(parts[0], leaf)
+            return
+        if not hasattr(self, parts[0]):
+            self.add_module(parts[0], torch.nn.ModuleList())
+        lst = getattr(self, parts[0])
+        assert int(parts[1]) == len(lst)
+        lst.append(leaf)
 
     def _layer(self, key):
-        mod = self
-        for p in key.split("."):
-            mod = getattr(mod, p)
-        return mod
+        parts = key.split(".")
+        mod = getattr(self, parts[0])
+        return mod[int(parts[1])] if len(parts) > 1 else mod
 
     @property
     def flops_per_point(self):

@@ -1,0 +1,86 @@
+"""CPU: host-side logic of the boundary (model recognition, sharding, failure without a GPU)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fields as ofields, synth
+
+
+def test_specs_agree_with_oracle():
+    from mirender import fields
+    for kind, name in fields.KIND_NAMES.items():
+        assert [(k, tuple(s)) for k, s in fields.SPECS[kind]] == [(k, tuple(s)) for k, s in ofields.SPECS[name]]
+        assert fields.MACS[kind] == ofields.MACS[name]
+    assert fields.FLOPS_PER_POINT[fields.NERF] == 1182976
+    assert fields.FLOPS_PER_POINT[fields.SIREN_NERF] == 1119232
+    assert fields.FLOPS_PER_POINT[fields.FILM_SIREN_NERF] == 1053696
+
+
+@pytest.mark.parametrize("name", ["nerf", "siren_nerf", "film_siren_nerf", "film_siren_nerf_nodir", "tiny_nerf"])
+def test_detect_kind_by_layout(name):
+    from mirender import fields
+    sd = synth.state_dict(name, seed=0)
+    assert fields.KIND_NAMES[fields.detect_kind(sd)] == name
+    bad = dict(sd)
+    bad.pop(next(iter(bad)))
+    assert fields.detect_kind(bad) is None
+    wrong = {k: (v if i else torch.zeros(7, 7)) for i, (k, v) in enumerate(sd.items())}
+    assert fields.detect_kind(wrong) is None
+
+
+def test_module_families_have_reference_keys_and_init():
+    from mirender import fields
+    torch.manual_seed(0)
+    for cls, name in ((fields.NeRF, "nerf"), (fields.SirenNeRF, "siren_nerf"), (fields.TinyNeRF, "tiny_nerf"),
+                      (fields.FilmSirenNeRF, "film_siren_nerf")):
+        m = cls()
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == \
+            {k: tuple(v) for k, v in ofields.param_shapes(name).items()}
+        m.load_state_dict(synth.state_dict(name, seed=1))          # reference-layout checkpoints load
+    m = fields.FilmSirenNeRF(use_dir=False)
+    assert tuple(m.hidden_layer_rgb.weight.shape) == (256, 256) and m.use_dir is False
+    # initialiser ranges (nerf/nerf.py:25-28,114-117,134; pi_GAN/modules.py:27-31)
+    n = fields.NeRF()
+    assert float(n.layers_pos[0].weight.abs().max()) <= np.sqrt(2) * np.sqrt(6 / (60 + 256)) + 1e-6
+    assert float(n.layers_pos[0].bias.abs().max()) == 0
+    s = fields.SirenNeRF()
+    assert float(s.layers_pos[0].weight.abs().max()) <= 1 / 30 + 1e-7
+    assert float(s.layers_pos[1].weight.abs().max()) <= np.sqrt(6 / 256) / 30 + 1e-7
+    f = fields.FilmSirenNeRF()
+    assert float(f.input_layer.weight.abs().max()) <= 1 / 3 + 1e-7
+
+
+def test_no_cpu_fallback():
+    """Without a ROCm device the product refuses to run (it must never fall back to PyTorch/CPU)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mirender import _lib, fields, render_core
+    m = fields.NeRF()
+    with pytest.raises(_lib.MiRenderError):
+        render_core.render_rays(torch.zeros(4, 2, 3), 2.0, 6.0, m, m, 8, 8)
+    with pytest.raises(_lib.MiRenderError):
+        m(torch.zeros(4, 6))
+    with pytest.raises((_lib.MiRenderError, RuntimeError)):
+        render_core.get_rays(4, 4, 5.0, np.eye(4, dtype=np.float32))
+
+
+def test_shard_ranges_partition():
+    from mirender.dist import shard_range
+    for total in (640000, 160000, 10, 7, 1):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_film_table_from_reference_style_params():
+    from mirender import fields
+    m = fields.FilmSirenNeRF()
+    with pytest.raises(ValueError):
+        fields.film_table(m)
+    mapping = synth.film_params(1, seed=3)[0]
+    m.set_film_params(mapping)                       # list of 9 (gamma, beta) chunks, pi_GAN/modules.py:96-99
+    assert len(m.film_params) == 9 and m.film_params[0][0].shape == (256,)
+    assert torch.equal(fields.film_table(m)[0], mapping)
