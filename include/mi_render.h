@@ -121,6 +121,38 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
                    const float* t_rand, uint64_t seed, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f,
                    void* workspace, void* stream);
 
+/* ---- training: what autograd does for the reference (train_nerf.py:151-168) ------------------ */
+
+/* Backward of raw_to_outputs (nerf/render.py:91-101): dL/d(rgb, depth, acc) -> dL/d(raw) [n,S,4].
+ * Any of g_rgb [n,3], g_depth [n], g_acc [n] may be NULL (= zero).  z and rays carry no gradient
+ * (z_samples is detached at render.py:141). */
+int mi_composite_bwd(int64_t n, int n_samples, const float* raw, const float* z, const float* rays,
+                     const float* g_rgb, const float* g_depth, const float* g_acc, float* g_raw, void* stream);
+
+/* Transposed weight stream for the backward chain (second packed buffer, refreshed with the weights). */
+int64_t mi_field_packed_bwd_floats(int kind);
+int mi_field_pack_bwd(int kind, const float* const* params, int n_params, float* packed_bwd, void* stream);
+
+/* Per-point sizes (floats) of the training buffers, or -1 if the kind has no backward yet:
+ * acts = layer inputs saved by the training forward; grads = per-layer dA written by the backward chain.
+ * mi_field_bwd_partial_floats(points) = scratch for the dW slab partial sums. */
+int64_t mi_field_train_acts_floats(int kind);
+int64_t mi_field_train_grads_floats(int kind);
+int64_t mi_field_bwd_partial_floats(int64_t points);
+
+/* mi_field_eval_rays that also saves every linear layer's input into `acts`
+ * [mi_field_train_acts_floats(kind) * points] (points = n_groups*rays_per_group*n_samples). */
+int mi_field_eval_rays_train(int kind, const float* packed, const float* film, const float* rays, const float* z,
+                             int64_t n_groups, int64_t rays_per_group, int n_samples, float* raw, float* acts,
+                             void* stream);
+
+/* Backward of network(inputs) over `points` points: g_raw [points,4] = dL/d(raw) -> parameter gradients.
+ * grad_params: HOST array of n_params device pointers (torch layouts, state-dict order), OVERWRITTEN.
+ * grads_ws: [mi_field_train_grads_floats(kind) * points], partial_ws: mi_field_bwd_partial_floats(points). */
+int mi_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads_ws, const float* raw,
+                      const float* g_raw, int64_t points, float* partial_ws, float* const* grad_params,
+                      int n_params, void* stream);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 
 /* HIP events owned by the library's HIP runtime (the one the kernels launch on), so a host

@@ -29,8 +29,9 @@ int check_launch(const char* what) {
     return MI_OK;
 }
 
-// implemented in field_mlp.hip / render_stages.hip
+// implemented in field_mlp.hip / field_mlp_bwd.hip
 const PackTable* host_table(int kind);
+const PackTable* host_table_bwd(int kind);
 static const int kNumLayers[MI_FIELD_KINDS] = {12, 12, 11, 11, 7};
 // multiply-accumulates of the linear layers per point (a6, a7, a8)
 static const int64_t kMacs[MI_FIELD_KINDS] = {591488, 559616, 526848, 526080, 248448};
@@ -42,7 +43,8 @@ static bool bad_kind(int kind) {
 static bool is_film(int kind) { return kind == MI_FIELD_FILM_SIREN_NERF || kind == MI_FIELD_FILM_SIREN_NERF_NODIR; }
 
 static int eval_common(int kind, const float* packed, const float* film, const float* a, const float* z,
-                       int64_t n_groups, int64_t ppg, int64_t rpg, int S, int mode, float* out, hipStream_t s) {
+                       int64_t n_groups, int64_t ppg, int64_t rpg, int S, int mode, float* out, hipStream_t s,
+                       float* save = nullptr) {
     if (bad_kind(kind)) return MI_EINVAL;
     if (!packed || !a || !out || (mode == 1 && !z)) { set_error("null pointer argument"); return MI_EINVAL; }
     if (is_film(kind) && !film) { set_error("FiLM kind needs a film table"); return MI_EINVAL; }
@@ -51,7 +53,7 @@ static int eval_common(int kind, const float* packed, const float* film, const f
     MlpArgs args;
     args.packed = packed; args.film = is_film(kind) ? film : nullptr; args.a = a; args.z = z; args.out = out;
     args.points_per_group = ppg; args.rays_per_group = rpg; args.tiles_per_group = (ppg + 127) / 128;
-    args.n_samples = S; args.mode = mode;
+    args.n_samples = S; args.mode = mode; args.save = save; args.save_points = n_groups * ppg;
     return launch_mlp(kind, args, n_groups, s);
 }
 
@@ -181,6 +183,46 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
         return rc;
     if (g_mlp_ev[3]) (void)hipEventRecord(g_mlp_ev[3], hs);
     return mi_composite(n, S, raw_f, z_f, rays, rgb_f, depth_f, acc_f, nullptr, stream);
+}
+
+int mi_composite_bwd(int64_t n, int n_samples, const float* raw, const float* z, const float* rays,
+                     const float* g_rgb, const float* g_depth, const float* g_acc, float* g_raw, void* stream) {
+    if (n < 0 || n_samples < 1 || !raw || !z || !rays || !g_raw) { set_error("mi_composite_bwd: bad arguments"); return MI_EINVAL; }
+    return launch_composite_bwd(n, n_samples, raw, z, rays, g_rgb, g_depth, g_acc, g_raw, (hipStream_t)stream);
+}
+
+int64_t mi_field_packed_bwd_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : packed_floats(*host_table_bwd(kind)); }
+
+int mi_field_pack_bwd(int kind, const float* const* params, int n_params, float* packed_bwd, void* stream) {
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (!params || !packed_bwd || n_params != 2 * kNumLayers[kind]) { set_error("mi_field_pack_bwd: bad arguments"); return MI_EINVAL; }
+    return launch_pack_bwd(kind, params, n_params, packed_bwd, (hipStream_t)stream);
+}
+
+int64_t mi_field_train_acts_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : train_acts_floats(kind); }
+int64_t mi_field_train_grads_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : train_grads_floats(kind); }
+int64_t mi_field_bwd_partial_floats(int64_t points) { return bwd_partial_floats(points); }
+
+int mi_field_eval_rays_train(int kind, const float* packed, const float* film, const float* rays, const float* z,
+                             int64_t n_groups, int64_t rays_per_group, int n_samples, float* raw, float* acts,
+                             void* stream) {
+    if (n_samples <= 0 || !acts) { set_error("mi_field_eval_rays_train: bad arguments"); return MI_EINVAL; }
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (train_acts_floats(kind) < 0) { set_error("kind %d has no training path yet", kind); return MI_EINVAL; }
+    return eval_common(kind, packed, film, rays, z, n_groups, rays_per_group * n_samples, rays_per_group, n_samples, 1,
+                       raw, (hipStream_t)stream, acts);
+}
+
+int mi_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads_ws, const float* raw,
+                      const float* g_raw, int64_t points, float* partial_ws, float* const* grad_params,
+                      int n_params, void* stream) {
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (!packed_bwd || !acts || !grads_ws || !raw || !g_raw || !partial_ws || !grad_params ||
+        n_params != 2 * kNumLayers[kind]) { set_error("mi_field_backward: bad arguments"); return MI_EINVAL; }
+    for (int i = 0; i < n_params; ++i)
+        if (!grad_params[i]) { set_error("gradient pointer %d is null", i); return MI_EINVAL; }
+    return launch_field_backward(kind, packed_bwd, acts, grads_ws, raw, g_raw, points, partial_ws, grad_params,
+                                 (hipStream_t)stream);
 }
 
 void* mi_event_create(void) {

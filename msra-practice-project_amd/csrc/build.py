@@ -18,11 +18,12 @@ ARCH = "gfx950"
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 SOURCES = {
     "field_mlp.hip": [],
+    "field_mlp_bwd.hip": [],
     # un-fused mul/add like the torch / NumPy ops these kernels restate
     "render_stages.hip": ["-ffp-contract=off"],
     "api.hip": [],
 }
-HEADERS = ["field_layout.h", "mi_common.h", os.path.join("..", "..", "include", "mi_render.h")]
+HEADERS = ["field_layout.h", "mi_common.h", "mi_math.h", "field_mlp_device.h", os.path.join("..", "..", "include", "mi_render.h")]
 
 
 def _stale(target, deps):

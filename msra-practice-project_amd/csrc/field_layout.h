@@ -32,12 +32,12 @@ enum ItemType : int { ITEM_VEC = 0, ITEM_PLAIN = 1, ITEM_CHUNK = 2 };
 struct PackItem {
     int type;          // ItemType
     int param;         // index into params[] (weight or bias tensor)
-    int ld;            // row stride of the source (weights: in_features; bias: 0)
-    int offset;        // VEC: start offset into source; CHUNK: first column (col0)
-    int stride;        // VEC: element stride between consecutive features
-    int n_valid;       // VEC/PLAIN: valid features; CHUNK: valid columns from col0 (<=32)
-    int rows_valid;    // CHUNK: valid output rows
-    int mb;            // CHUNK: output blocks (8 or 4)
+    int ld;            // CHUNK: source stride between MFMA rows (forward: in_features; transposed: 1)
+    int offset;        // VEC: start offset into source; CHUNK: offset of element (row 0, col 0)
+    int stride;        // VEC: stride between consecutive features; CHUNK: stride between K columns
+    int n_valid;       // VEC/PLAIN: valid features; CHUNK: valid K columns (<=32)
+    int rows_valid;    // CHUNK: valid MFMA rows
+    int mb;            // CHUNK: MFMA row blocks (8 or 4)
 };
 
 constexpr int kMaxItems = 112;
@@ -88,7 +88,15 @@ struct TableBuilder {
     constexpr void chunks(int layer, int ld, int col0, int ncols, int rows, int mb) {
         for (int c = 0; c < ncols; c += 32) {
             int nv = ncols - c < 32 ? ncols - c : 32;
-            push({ITEM_CHUNK, 2 * layer, ld, col0 + c, 0, nv, rows, mb}, mb * 1024);
+            push({ITEM_CHUNK, 2 * layer, ld, col0 + c, 1, nv, rows, mb}, mb * 1024);
+        }
+    }
+    // K blocks of the TRANSPOSED weight of layer i for the backward chain dX = W^T dA:
+    // MFMA rows = input features [hcol0, hcol0+rows) of W, K = W's n_out output features
+    constexpr void chunks_t(int layer, int ld, int hcol0, int rows, int n_out, int mb) {
+        for (int c = 0; c < n_out; c += 32) {
+            int nv = n_out - c < 32 ? n_out - c : 32;
+            push({ITEM_CHUNK, 2 * layer, 1, hcol0 + c * ld, ld, nv, rows, mb}, mb * 1024);
         }
     }
 };
@@ -149,6 +157,73 @@ constexpr PackTable build_film(bool use_dir) {
     b.chunks(9, ld, 0, 256, 256, 8);
     return b.t;
 }
+
+// ---- backward-chain streams (dX = W^T dA per layer, reverse order), consumed by field_mlp_bwd.hip ----
+// NeRF: [rgb head rows x3] | layers_dir.1^T (h part) | [sigma head row] layers_dir.0^T | layers_pos.7^T .. 1^T
+constexpr PackTable build_nerf_bwd() {
+    TableBuilder b;
+    b.wrow(11, 128, 0, 0, 128); b.wrow(11, 128, 1, 0, 128); b.wrow(11, 128, 2, 0, 128);
+    b.chunks_t(9, 280, 0, 256, 128, 8);
+    b.wrow(10, 256, 0, 0, 256);
+    b.chunks_t(8, 256, 0, 256, 256, 8);
+    b.chunks_t(7, 256, 0, 256, 256, 8);
+    b.chunks_t(6, 256, 0, 256, 256, 8);
+    b.chunks_t(5, 316, 60, 256, 256, 8);
+    for (int l = 4; l >= 1; --l) b.chunks_t(l, 256, 0, 256, 256, 8);
+    return b.t;
+}
+
+// TinyNeRF: [rgb rows x3] | layers_dir.0^T (h part) with [sigma row] | layers_pos.3^T .. 1^T
+constexpr PackTable build_tiny_nerf_bwd() {
+    TableBuilder b;
+    b.wrow(6, 128, 0, 0, 128); b.wrow(6, 128, 1, 0, 128); b.wrow(6, 128, 2, 0, 128); b.wrow(5, 256, 0, 0, 256);
+    b.chunks_t(4, 280, 0, 256, 128, 8);
+    for (int l = 3; l >= 1; --l) b.chunks_t(l, 256, 0, 256, 256, 8);
+    return b.t;
+}
+
+// SirenNeRF: same chain as NeRF (K=3 inputs need no dX); layers_pos.5's h part starts at column 3
+constexpr PackTable build_siren_nerf_bwd() {
+    TableBuilder b;
+    b.wrow(11, 128, 0, 0, 128); b.wrow(11, 128, 1, 0, 128); b.wrow(11, 128, 2, 0, 128);
+    b.chunks_t(9, 259, 0, 256, 128, 8);
+    b.wrow(10, 256, 0, 0, 256);
+    b.chunks_t(8, 256, 0, 256, 256, 8);
+    b.chunks_t(7, 256, 0, 256, 256, 8);
+    b.chunks_t(6, 256, 0, 256, 256, 8);
+    b.chunks_t(5, 259, 3, 256, 256, 8);
+    for (int l = 4; l >= 1; --l) b.chunks_t(l, 256, 0, 256, 256, 8);
+    return b.t;
+}
+
+// FilmSirenNeRF: [rgb rows x3 over 256 features] | hidden_layer_rgb^T (h part) with [sigma row] | hidden 6..0 ^T
+constexpr PackTable build_film_bwd(bool use_dir) {
+    TableBuilder b;
+    b.wrow(10, 256, 0, 0, 256); b.wrow(10, 256, 1, 0, 256); b.wrow(10, 256, 2, 0, 256); b.wrow(8, 256, 0, 0, 256);
+    b.chunks_t(9, use_dir ? 259 : 256, 0, 256, 256, 8);
+    for (int l = 7; l >= 1; --l) b.chunks_t(l, 256, 0, 256, 256, 8);
+    return b.t;
+}
+
+// ---- training buffers: per-point row-major regions [points][width], region r at offset_r * points ------
+// acts  = layer inputs saved by the forward (what dW = dA X^T and the activation derivatives need)
+// grads = dA of every linear layer written by the backward chain (+ 4 head pre-activation grads)
+struct RegionLayout { int n; int width[40]; };
+constexpr int region_offset(const RegionLayout& L, int idx) {
+    int o = 0;
+    for (int i = 0; i < idx; ++i) o += L.width[i];
+    return o;
+}
+constexpr int region_total(const RegionLayout& L) { return region_offset(L, L.n); }
+
+// NeRF acts: 0 E_pos(64) | 1..8 H1..H8 (post-ReLU outputs of layers_pos.0..7) | 9 G (layers_dir.0 out) |
+//            10 E_dir(32) | 11 H_d (post-ReLU layers_dir.1, 128)
+constexpr RegionLayout nerf_acts() { return {12, {64, 256, 256, 256, 256, 256, 256, 256, 256, 256, 32, 128}}; }
+// NeRF grads: 0..7 dA of layers_pos.0..7 | 8 dA layers_dir.0 | 9 dA layers_dir.1 (128) | 10 head pre-act grads (4)
+constexpr RegionLayout nerf_grads() { return {11, {256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 4}}; }
+// TinyNeRF acts: 0 E_pos | 1..4 H1..H4 | 5 E_dir(32) | 6 H_d(128); grads: 0..3 | 4 dA dir (128) | 5 heads (4)
+constexpr RegionLayout tiny_acts() { return {7, {64, 256, 256, 256, 256, 32, 128}}; }
+constexpr RegionLayout tiny_grads() { return {6, {256, 256, 256, 256, 128, 4}}; }
 
 constexpr int packed_floats(const PackTable& t) {
     const PackItem& last = t.item[t.n_items - 1];

@@ -1,0 +1,449 @@
+// field_mlp_bwd.hip - backward of the fused field MLP (gfx950): what autograd does for
+// `network(inputs)` inside run_network (reference nerf/render.py:72-74) when train_nerf.py:168 /
+// pi_GAN/train.py call loss.backward().
+//
+// Three kinds of kernels, all fp32:
+//   1. backward CHAIN (one per field kind): same structure as the forward - 128 points per workgroup,
+//      features on MFMA rows, the accumulators of dX_l = W_l^T dA_l are, after the activation derivative,
+//      the B operands of the next (earlier) layer; transposed weights stream through LDS from a second
+//      packed stream (field_layout.h build_*_bwd).  It reads the saved layer inputs for the activation
+//      derivative and writes dA of every linear layer as [point][feature] rows.
+//   2. dW GEMM: dW_l[M,K] = sum_p dA_l[p,:]^T X_l[p,:] - a plain GEMM whose contraction is over POINTS.
+//      Features sit on the MFMA lanes (one float4 load per lane gives the operands of four 32-wide blocks
+//      straight from the row-major rows, no LDS), each workgroup reduces a slab of points into a full
+//      256x256 tile held in accumulators (256 registers per lane), slabs are combined by a second kernel in
+//      a fixed order (deterministic, no atomics).  Bias gradients ride along as column sums of dA.
+//   3. head gradients (1- and 3-row weights): VALU reduction over point slabs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "field_mlp_device.h"
+
+namespace mi {
+
+__constant__ PackTable c_tabb_nerf = build_nerf_bwd();
+__constant__ PackTable c_tabb_siren = build_siren_nerf_bwd();
+__constant__ PackTable c_tabb_film = build_film_bwd(true);
+__constant__ PackTable c_tabb_film_nodir = build_film_bwd(false);
+__constant__ PackTable c_tabb_tiny = build_tiny_nerf_bwd();
+
+static constexpr PackTable h_tabb_nerf = build_nerf_bwd();
+static constexpr PackTable h_tabb_siren = build_siren_nerf_bwd();
+static constexpr PackTable h_tabb_film = build_film_bwd(true);
+static constexpr PackTable h_tabb_film_nodir = build_film_bwd(false);
+static constexpr PackTable h_tabb_tiny = build_tiny_nerf_bwd();
+
+const PackTable* host_table_bwd(int kind) {
+    switch (kind) {
+        case 0: return &h_tabb_nerf;
+        case 1: return &h_tabb_siren;
+        case 2: return &h_tabb_film;
+        case 3: return &h_tabb_film_nodir;
+        case 4: return &h_tabb_tiny;
+    }
+    return nullptr;
+}
+
+struct ParamPtrsB { const float* p[24]; };
+
+__device__ __forceinline__ const PackTable& dev_table_bwd(int kind) {
+    switch (kind) {
+        case 0: return c_tabb_nerf;
+        case 1: return c_tabb_siren;
+        case 2: return c_tabb_film;
+        case 3: return c_tabb_film_nodir;
+        default: return c_tabb_tiny;
+    }
+}
+
+__global__ void pack_bwd_kernel(int kind, ParamPtrsB pp, float* __restrict__ dst) {
+    const PackTable& t = dev_table_bwd(kind);
+    const int it = blockIdx.y;
+    if (it >= t.n_items) return;
+    const PackItem item = t.item[it];
+    float* out = dst + t.dst_off[it];
+    const float* src = pp.p[item.param];
+    if (item.type == ITEM_CHUNK) {
+        const int total = item.mb * 1024;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += 32 * 256) {
+            int q = idx & 3, lane = (idx >> 2) & 63, rm = idx >> 8;
+            int m = rm % item.mb, rg = rm / item.mb;
+            int row = 32 * m + (lane & 31);
+            int c = 8 * rg + 4 * (lane >> 5) + q;
+            float v = 0.f;
+            if (row < item.rows_valid && c < item.n_valid)
+                v = src[(int64_t)row * item.ld + item.offset + (int64_t)c * item.stride];
+            out[idx] = v;
+        }
+    } else if (blockIdx.x == 0) {
+        const int f = threadIdx.x;
+        if (item.type == ITEM_VEC) out[vec_slot(f)] = f < item.n_valid ? src[item.offset + (int64_t)f * item.stride] : 0.f;
+        else out[f] = f < item.n_valid ? src[f] : 0.f;
+    }
+}
+
+struct BwdArgs {
+    const float* packed;     // backward stream
+    const float* acts;       // saved layer inputs (regions x points)
+    float* grads;            // dA regions x points (written here)
+    const float* raw;        // [P,4] forward outputs (rgb post-sigmoid, sigma post-ReLU)
+    const float* g_raw;      // [P,4] dL/d(raw)
+    int64_t points;
+};
+
+// dA = dX (.) relu'(H) with H the saved post-ReLU activation; stores dA rows and leaves them in X.
+template <int MB>
+__device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ H,
+                                               float* __restrict__ dA, int64_t ld, int64_t p, bool valid, int h) {
+    const f32x4* hrow = reinterpret_cast<const f32x4*>(H + p * ld + 4 * h);
+    f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 hv = hrow[m * 8 + rg * 2];
+            f32x4 o;
+            o.x = hv.x > 0.f ? dX[m][4 * rg + 0] : 0.f;
+            o.y = hv.y > 0.f ? dX[m][4 * rg + 1] : 0.f;
+            o.z = hv.z > 0.f ? dX[m][4 * rg + 2] : 0.f;
+            o.w = hv.w > 0.f ? dX[m][4 * rg + 3] : 0.f;
+            X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
+            if (valid) drow[m * 8 + rg * 2] = o;
+        }
+}
+
+// =========================================================================================
+// NeRF / TinyNeRF backward chain (reverse of nerf/nerf.py:75-94)
+// =========================================================================================
+template <bool TINY>
+__global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Ctx c;
+    c.smem = smem; c.wp = a.packed; c.film = nullptr;
+    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.h = c.lane >> 5;
+    constexpr RegionLayout AL = TINY ? tiny_acts() : nerf_acts();
+    constexpr RegionLayout GL = TINY ? tiny_grads() : nerf_grads();
+    constexpr int kHeadAux = TINY ? 4 : 3;                 // rgb rows (+ sigma row for TinyNeRF)
+    const int64_t P = a.points;
+    issue_stage<kHeadAux, 32, false>(c, 0, 0, 0);
+
+    const int64_t local = (int64_t)blockIdx.x * 128 + c.wave * 32 + (c.lane & 31);
+    const bool valid = local < P;
+    const int64_t p = valid ? local : P - 1;
+    const f32x4 g = reinterpret_cast<const f32x4*>(a.g_raw)[p];
+    const f32x4 o = reinterpret_cast<const f32x4*>(a.raw)[p];
+    // heads: rgb = sigmoid(pre), sigma = relu(pre)
+    const float d0 = g.x * o.x * (1.f - o.x), d1 = g.y * o.y * (1.f - o.y), d2 = g.z * o.z * (1.f - o.z);
+    const float ds = o.w > 0.f ? g.w : 0.f;
+    if (valid && c.h == 0)
+        reinterpret_cast<f32x4*>(a.grads + (int64_t)region_offset(GL, GL.n - 1) * P)[p] = f32x4{d0, d1, d2, ds};
+
+    f32x16 X[8], acc[8];
+    const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
+    const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
+    const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
+
+    __syncthreads();                                        // head rows (and K block 0) have landed
+    {   // dH_d = W_rgb^T d_pre_rgb   (128 features)
+        const lds4_t pw = lds_base(smem + kLdsAux0 + c.h * 16);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 w0 = pw[0 * 64 + m * 8 + rg], w1 = pw[1 * 64 + m * 8 + rg], w2 = pw[2 * 64 + m * 8 + rg];
+                acc[m][4 * rg + 0] = fmaf(w2.x, d2, fmaf(w1.x, d1, w0.x * d0));
+                acc[m][4 * rg + 1] = fmaf(w2.y, d2, fmaf(w1.y, d1, w0.y * d0));
+                acc[m][4 * rg + 2] = fmaf(w2.z, d2, fmaf(w1.z, d1, w0.z * d0));
+                acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
+            }
+    }
+    relu_bwd_store<4>(acc, X, acts(TINY ? 6 : 11), grads(TINY ? 4 : 9), 128, p, valid, c.h);   // dA of the dir layer
+
+    int slot = 0;
+    if constexpr (!TINY) {
+        // layers_dir[1]^T: dG = W[:, :256]^T dA (K = 128)
+        mma_layer_fn<4, 8, 0, 1, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);
+        slot ^= 1;
+        // layers_dir[0] is linear: dA = dG
+#pragma unroll
+        for (int m = 0; m < 8; ++m) X[m] = acc[m];
+        store_rows<8>(grads(8), 256, p, valid, c.h, X);
+        // layers_dir[0]^T, plus the sigma head's contribution to dH8
+        mma_layer_fn<8, 8, 0, 0, 32, false>(
+            c, slot, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0 + slot * kLdsAux, 0, c.h, ds, x); },
+            sel_x, acc);
+        slot ^= 1;
+        relu_bwd_store<8>(acc, X, acts(8), grads(7), 256, p, valid, c.h);                     // dA7 = dH8 (.) [H8>0]
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L7^T
+        relu_bwd_store<8>(acc, X, acts(7), grads(6), 256, p, valid, c.h);
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L6^T
+        relu_bwd_store<8>(acc, X, acts(6), grads(5), 256, p, valid, c.h);
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L5^T (h part)
+        relu_bwd_store<8>(acc, X, acts(5), grads(4), 256, p, valid, c.h);
+#pragma unroll 1
+        for (int l = 4; l >= 2; --l) {                                                         // L4^T .. L2^T
+            mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);
+            relu_bwd_store<8>(acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
+                              a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, c.h);
+        }
+        mma_layer_fn<8, 8, 0, 0, 0, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);   // L1^T
+        relu_bwd_store<8>(acc, X, acts(1), grads(0), 256, p, valid, c.h);
+    } else {
+        // dir layer^T with the sigma head's contribution to dH4 (sigma row is aux piece 3 of slot 0)
+        mma_layer_fn<4, 8, 0, 0, 32, false>(
+            c, slot, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0, 3, c.h, ds, x); }, sel_x, acc);
+        relu_bwd_store<8>(acc, X, acts(4), grads(3), 256, p, valid, c.h);
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L3^T
+        relu_bwd_store<8>(acc, X, acts(3), grads(2), 256, p, valid, c.h);
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L2^T
+        relu_bwd_store<8>(acc, X, acts(2), grads(1), 256, p, valid, c.h);
+        mma_layer_fn<8, 8, 0, 0, 0, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);   // L1^T
+        relu_bwd_store<8>(acc, X, acts(1), grads(0), 256, p, valid, c.h);
+    }
+}
+
+// =========================================================================================
+// dW GEMM over points.  A side: dA[p][a_col0 + 128*wm + 4*i + c], B side: X[p][x_col0 + 32*CB*wk + CB*j + d].
+// acc[c][d] (+)= A_c (x) B_d per point pair.  Workgroup = 4 waves = tiles (WM x WK) x k-split.
+// partial[(slab*KS + ks)][TM][TK] row-major, bias_partial[(slab*KS + ks)][TM].
+// =========================================================================================
+template <int CB, int WM, int WK>
+__global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict__ dA, int lda, int a_col0,
+                                                         const float* __restrict__ X, int ldx, int x_col0,
+                                                         int64_t P, int slab_pts, float* __restrict__ partial,
+                                                         float* __restrict__ bias_partial) {
+    constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
+    typedef float bvec __attribute__((ext_vector_type(CB)));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int tile = wave % TILES, ks = wave / TILES;
+    const int wm = tile / WK, wk = tile % WK;
+    const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
+    const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
+    const float* arow = dA + a_col0 + 128 * wm + 4 * i;
+    const float* brow = X + x_col0 + 32 * CB * wk + CB * i;
+
+    f32x16 acc[4][CB];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int d = 0; d < CB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    constexpr int U = 4;    // point pairs in flight per wave
+    for (int64_t t0 = p0 + 2 * ks; t0 < p1; t0 += 2 * KS * U) {
+        f32x4 av[U];
+        bvec bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t p = t0 + 2 * KS * u + h;
+            if (p < p1) {
+                av[u] = *reinterpret_cast<const f32x4*>(arow + p * lda);
+                bv[u] = *reinterpret_cast<const bvec*>(brow + p * ldx);
+            } else {
+                av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < CB; ++d) bv[u][d] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bsum += av[u];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < CB; ++d)
+                    acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+        }
+    }
+    // write the partial tile: D[row i'][col j] on lane (j, h), reg r: i' = (r&3) + 8*(r>>2) + 4*h
+    float* out = partial + ((int64_t)blockIdx.x * KS + ks) * TM * TK;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ip = (r & 3) + 8 * (r >> 2) + 4 * h;
+            bvec v;
+#pragma unroll
+            for (int d = 0; d < CB; ++d) v[d] = acc[c][d][r];
+            *reinterpret_cast<bvec*>(out + (int64_t)(128 * wm + 4 * ip + c) * TK + 32 * CB * wk + CB * i) = v;
+        }
+    if (bias_partial && wk == 0) {
+        bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32);
+        bsum.z += __shfl_xor(bsum.z, 32); bsum.w += __shfl_xor(bsum.w, 32);
+        if (h == 0)
+            *reinterpret_cast<f32x4*>(bias_partial + ((int64_t)blockIdx.x * KS + ks) * TM + 128 * wm + 4 * i) = bsum;
+    }
+}
+
+// dst[row][dst_col0 + col] = sum over partials (fixed order), rows < rows_valid, cols < cols_valid
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int n_partials, int TM, int TK,
+                                       float* __restrict__ dst, int dst_ld, int dst_col0, int rows_valid,
+                                       int cols_valid) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= TM * TK) return;
+    const int row = idx / TK, col = idx % TK;
+    if (row >= rows_valid || col >= cols_valid) return;
+    float s = 0.f;
+    for (int k = 0; k < n_partials; ++k) s += partial[(int64_t)k * TM * TK + idx];
+    dst[(int64_t)row * dst_ld + dst_col0 + col] = s;
+}
+
+// head weight gradients: dW[c][f] = sum_p dpre[p][c0+c] * H[p][f] (c < NC <= 3), db[c] = sum_p dpre[p][c0+c].
+// grid = slabs, block = 256 threads = features.  partial[slab][4][256] (+ bias in row 3's unused... separate buf)
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ dpre, int c0, int nc,
+                                                        const float* __restrict__ H, int ldh, int F, int64_t P,
+                                                        int slab_pts, float* __restrict__ partial,
+                                                        float* __restrict__ bias_partial) {
+    const int f = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
+    const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (int64_t p = p0; p < p1; ++p) {
+        const float4 d = reinterpret_cast<const float4*>(dpre)[p];
+        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const float hv = f < F ? H[p * ldh + f] : 0.f;
+        a0 = fmaf(dv[c0], hv, a0); b0 += dv[c0];
+        if (nc > 1) { a1 = fmaf(dv[c0 + 1], hv, a1); b1 += dv[c0 + 1]; }
+        if (nc > 2) { a2 = fmaf(dv[c0 + 2], hv, a2); b2 += dv[c0 + 2]; }
+    }
+    float* out = partial + (int64_t)blockIdx.x * 4 * 256;
+    out[0 * 256 + f] = a0; out[1 * 256 + f] = a1; out[2 * 256 + f] = a2; out[3 * 256 + f] = 0.f;
+    if (f == 0) {
+        float* bo = bias_partial + (int64_t)blockIdx.x * 4;
+        bo[0] = b0; bo[1] = b1; bo[2] = b2; bo[3] = 0.f;
+    }
+}
+
+// ---- host orchestration ---------------------------------------------------------------------
+int launch_pack_bwd(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream) {
+    const PackTable* t = host_table_bwd(kind);
+    ParamPtrsB pp{};
+    for (int i = 0; i < n_params && i < 24; ++i) pp.p[i] = params[i];
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3(32, t->n_items), dim3(256), 0, stream, kind, pp, packed);
+    return check_launch("pack_bwd_kernel");
+}
+
+int64_t train_acts_floats(int kind) {
+    switch (kind) {
+        case 0: return region_total(nerf_acts());
+        case 4: return region_total(tiny_acts());
+    }
+    return -1;
+}
+int64_t train_grads_floats(int kind) {
+    switch (kind) {
+        case 0: return region_total(nerf_grads());
+        case 4: return region_total(tiny_grads());
+    }
+    return -1;
+}
+
+static int slab_points(int64_t P) {
+    int64_t s = (P + 511) / 512;           // aim at >= 512 workgroups
+    s = (s + 31) / 32 * 32;
+    if (s < 256) s = 256;
+    if (s > 4096) s = 4096;
+    return (int)s;
+}
+int64_t bwd_partial_floats(int64_t P) {
+    const int slab = slab_points(P);
+    const int64_t slabs = (P + slab - 1) / slab;
+    return slabs * 4 * (256 * 256 + 256);  // up to 4 k-split partial tiles + bias rows per slab
+}
+
+struct GemmJob {
+    int a_region, M;          // dA region, rows (256 or 128)
+    int x_region, x_col_valid, K;   // X region, valid columns, padded K (256, 64 or 32)
+    int w_param, w_ld, w_col0;      // destination weight grad [M, w_ld] at column w_col0
+    int b_param;                    // bias grad (or -1 when another job of the same layer writes it)
+};
+
+template <int CB, int WM, int WK>
+static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P, float* partial, float* gw, int w_ld,
+                    int w_col0, int rows_valid, int cols_valid, float* gb, hipStream_t stream) {
+    constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
+    const int slab = slab_points(P);
+    const int slabs = (int)((P + slab - 1) / slab);
+    float* bias_partial = partial + (int64_t)slabs * KS * TM * TK;
+    hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), 0, stream, dA, lda, 0, X, ldx, 0, P, slab,
+                       partial, gb ? bias_partial : nullptr);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((TM * TK + 255) / 256), dim3(256), 0, stream, partial, slabs * KS, TM,
+                       TK, gw, w_ld, w_col0, rows_valid, cols_valid);
+    if (gb)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3((TM + 255) / 256), dim3(256), 0, stream, bias_partial, slabs * KS,
+                           1, TM, gb, TM, 0, 1, rows_valid);
+    return check_launch("dw_gemm");
+}
+
+static int run_head(const float* dpre, int c0, int nc, const float* H, int ldh, int F, int64_t P, float* partial,
+                    float* gw, float* gb, hipStream_t stream) {
+    const int slab = slab_points(P);
+    const int slabs = (int)((P + slab - 1) / slab);
+    float* bias_partial = partial + (int64_t)slabs * 4 * 256;
+    hipLaunchKernelGGL(head_grad_kernel, dim3(slabs), dim3(256), 0, stream, dpre, c0, nc, H, ldh, F, P, slab, partial,
+                       bias_partial);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(4), dim3(256), 0, stream, partial, slabs, 4, 256, gw, F, 0, nc, F);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, bias_partial, slabs, 1, 4, gb, 4, 0, 1, nc);
+    return check_launch("head_grad");
+}
+
+// Backward of a NeRF / TinyNeRF field over P points.  grad_params[2i], [2i+1]: device pointers to the weight /
+// bias gradient tensors (torch layout), overwritten.
+int launch_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads, const float* raw,
+                          const float* g_raw, int64_t P, float* partial, float* const* gp, hipStream_t stream) {
+    if (P <= 0) return 0;
+    if (kind != 0 && kind != 4) { set_error("backward is implemented for NeRF / TinyNeRF kinds (got %d)", kind); return -1; }
+    static bool attr_done = false;
+    const size_t lds = kLdsFloats * sizeof(float);
+    if (!attr_done) {
+        const void* fns[] = {(const void*)nerf_bwd_kernel<false>, (const void*)nerf_bwd_kernel<true>};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                set_error("hipFuncSetAttribute failed"); return -2;
+            }
+        attr_done = true;
+    }
+    BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P};
+    const unsigned blocks = (unsigned)((P + 127) / 128);
+    int rc;
+    if (kind == 0) {
+        hipLaunchKernelGGL(nerf_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
+        if ((rc = check_launch("nerf_bwd_kernel"))) return rc;
+        constexpr RegionLayout AL = nerf_acts(), GL = nerf_grads();
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
+        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
+        // layers_pos.0: dA0 x E_pos
+        if ((rc = run_gemm<2, 2, 1>(G(0), 256, A(0), 64, P, partial, gp[0], 60, 0, 256, 60, gp[1], stream))) return rc;
+        for (int l = 1; l <= 7; ++l) {
+            const int ldw = l == 5 ? 316 : 256, col0 = l == 5 ? 60 : 0;
+            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(l), 256, P, partial, gp[2 * l], ldw, col0, 256, 256, gp[2 * l + 1], stream))) return rc;
+        }
+        if ((rc = run_gemm<2, 2, 1>(G(5), 256, A(0), 64, P, partial, gp[10], 316, 0, 256, 60, nullptr, stream))) return rc;
+        // layers_dir.0: dA x H8 ; layers_dir.1: dA(128) x [G | E_dir]
+        if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(8), 256, P, partial, gp[16], 256, 0, 256, 256, gp[17], stream))) return rc;
+        if ((rc = run_gemm<4, 1, 2>(G(9), 128, A(9), 256, P, partial, gp[18], 280, 0, 128, 256, gp[19], stream))) return rc;
+        if ((rc = run_gemm<1, 1, 1>(G(9), 128, A(10), 32, P, partial, gp[18], 280, 256, 128, 24, nullptr, stream))) return rc;
+        // heads: sigma (row 3 of dpre) x H8, rgb (rows 0..2) x H_d
+        if ((rc = run_head(G(10), 3, 1, A(8), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
+        if ((rc = run_head(G(10), 0, 3, A(11), 128, 128, P, partial, gp[22], gp[23], stream))) return rc;
+    } else {
+        hipLaunchKernelGGL(nerf_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
+        if ((rc = check_launch("nerf_bwd_kernel"))) return rc;
+        constexpr RegionLayout AL = tiny_acts(), GL = tiny_grads();
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
+        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
+        if ((rc = run_gemm<2, 2, 1>(G(0), 256, A(0), 64, P, partial, gp[0], 60, 0, 256, 60, gp[1], stream))) return rc;
+        for (int l = 1; l <= 3; ++l)
+            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(l), 256, P, partial, gp[2 * l], 256, 0, 256, 256, gp[2 * l + 1], stream))) return rc;
+        if ((rc = run_gemm<4, 1, 2>(G(4), 128, A(4), 256, P, partial, gp[8], 280, 0, 128, 256, gp[9], stream))) return rc;
+        if ((rc = run_gemm<1, 1, 1>(G(4), 128, A(5), 32, P, partial, gp[8], 280, 256, 128, 24, nullptr, stream))) return rc;
+        if ((rc = run_head(G(5), 3, 1, A(4), 256, 256, P, partial, gp[10], gp[11], stream))) return rc;
+        if ((rc = run_head(G(5), 0, 3, A(6), 128, 128, P, partial, gp[12], gp[13], stream))) return rc;
+    }
+    return 0;
+}
+
+}  // namespace mi

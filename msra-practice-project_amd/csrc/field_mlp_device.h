@@ -1,0 +1,314 @@
+// field_mlp_device.h - device building blocks shared by the fused field-MLP forward
+// (field_mlp.hip) and backward-chain (field_mlp_bwd.hip) kernels: LDS map, DMA stages, the 32-wide
+// K-block MFMA step, register<->row-major activation I/O.  See field_mlp.hip for the design.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "field_layout.h"
+#include "mi_common.h"
+#include "mi_math.h"
+
+namespace mi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MI_LDS __attribute__((address_space(3)))
+#define MI_GLB __attribute__((address_space(1)))
+typedef const MI_LDS f32x4* lds4_t;
+
+// Per-lane LDS base made opaque to the optimiser.  The aux / film regions sit above 64 KiB, out
+// of reach of the 16-bit ds_read immediate from LDS address 0; without this hipcc materialises
+// one address VGPR per read (hundreds, spilled to scratch).  With it: one VGPR + immediates.
+__device__ __forceinline__ lds4_t lds_base(const float* p) {
+    lds4_t q = (lds4_t)(const MI_LDS float*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
+// ---- LDS map (floats) ----------------------------------------------------------------------
+constexpr int kLdsChunk = 8192;                          // 32 KiB K-block buffer (MB = 8)
+constexpr int kLdsAux = kMaxAuxPieces * kPiece;          // 8 KiB per-layer aux slot
+constexpr int kLdsChunk0 = 0;
+constexpr int kLdsAux0 = 2 * kLdsChunk;
+constexpr int kLdsFilm0 = kLdsAux0 + 2 * kLdsAux;
+constexpr int kLdsFloats = kLdsFilm0 + 2 * kFilmRow;     // 21504 floats = 84 KiB
+
+enum Act : int { ACT_LINEAR = 0, ACT_RELU = 1, ACT_SIN30 = 2, ACT_FILM = 3 };
+
+struct Ctx {
+    float* smem;
+    const float* wp;        // next unread piece of the packed stream (wave-uniform)
+    const float* film;      // this group's FiLM table [9][512] or nullptr
+    int lane, wave, h;
+};
+
+// DMA n consecutive 1 KiB pieces g -> lds, split over the 4 waves.
+__device__ __forceinline__ void dma_pieces(const float* g, float* lds, int n, int wave, int lane) {
+#pragma unroll
+    for (int t0 = 0; t0 < n; t0 += 4) {
+        const int t = t0 + wave;
+        if (t < n)
+            __builtin_amdgcn_global_load_lds((const MI_GLB void*)(g + t * kPiece + lane * 4),
+                                             (MI_LDS void*)(lds + t * kPiece), 16, 0, 0);
+    }
+}
+
+// Issue the DMA of one stage: optional aux pieces (+ FiLM row) of a layer, then one K block.
+template <int N_AUX, int N_CHUNK_PIECES, bool FILM>
+__device__ __forceinline__ void issue_stage(Ctx& c, int aux_slot, int chunk_buf, int film_layer) {
+    if constexpr (N_AUX > 0) {
+        dma_pieces(c.wp, c.smem + kLdsAux0 + aux_slot * kLdsAux, N_AUX, c.wave, c.lane);
+        c.wp += N_AUX * kPiece;
+        if constexpr (FILM)
+            dma_pieces(c.film + film_layer * kFilmRow, c.smem + kLdsFilm0 + aux_slot * kFilmRow, 2, c.wave, c.lane);
+    }
+    if constexpr (N_CHUNK_PIECES > 0) {
+        dma_pieces(c.wp, c.smem + kLdsChunk0 + chunk_buf * kLdsChunk, N_CHUNK_PIECES, c.wave, c.lane);
+        c.wp += N_CHUNK_PIECES * kPiece;
+    }
+}
+
+// 32-wide K block: acc[m] += W[32m.., kblock] * B, A fragments from LDS (4 MFMAs per b128 read).
+template <int MB>
+__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8]) {
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + lane;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const f32x4 a = a4[(rg * MB + m) * 64];
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * rg + 0], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * rg + 1], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * rg + 2], acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * rg + 3], acc[m], 0, 0, 0);
+        }
+    }
+}
+
+// acc = bias (+ W3 * xyz for the K=3 inputs of Siren/FiLM nets), from the layer's aux slot.
+template <int MB, bool K3>
+__device__ __forceinline__ void init_acc(const float* aux, int h, int k3_piece, float x, float y, float z,
+                                         f32x16 (&acc)[8]) {
+    const lds4_t pb = lds_base(aux + h * 16);       // VEC piece entry ((m*2+h)*4 + rg) in f32x4 units
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 t = pb[m * 8 + rg];
+            if constexpr (K3) {
+                const f32x4 w0 = pb[(k3_piece + 0) * 64 + m * 8 + rg];
+                const f32x4 w1 = pb[(k3_piece + 1) * 64 + m * 8 + rg];
+                const f32x4 w2 = pb[(k3_piece + 2) * 64 + m * 8 + rg];
+                t.x = fmaf(w2.x, z, fmaf(w1.x, y, fmaf(w0.x, x, t.x)));
+                t.y = fmaf(w2.y, z, fmaf(w1.y, y, fmaf(w0.y, x, t.y)));
+                t.z = fmaf(w2.z, z, fmaf(w1.z, y, fmaf(w0.z, x, t.z)));
+                t.w = fmaf(w2.w, z, fmaf(w1.w, y, fmaf(w0.w, x, t.w)));
+            }
+            acc[m][4 * rg + 0] = t.x; acc[m][4 * rg + 1] = t.y; acc[m][4 * rg + 2] = t.z; acc[m][4 * rg + 3] = t.w;
+        }
+    }
+}
+
+// Activation epilogue: X = act(acc).  FiLM reads gamma|beta of this layer from the film slot.
+template <int MB, int ACT>
+__device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h) {
+    lds4_t pf = nullptr;
+    if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);   // gamma at f, beta at 256 + f
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 g, b;
+            if constexpr (ACT == ACT_FILM) {
+                g = pf[m * 8 + rg * 2];
+                b = pf[64 + m * 8 + rg * 2];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = acc[m][4 * rg + q];
+                float o;
+                if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
+                else if constexpr (ACT == ACT_SIN30) o = fast_sin(__fmul_rn(30.f, v));
+                else if constexpr (ACT == ACT_FILM) o = fast_sin(__fmul_rn(30.f, __fadd_rn(__fmul_rn(g[q], v), b[q])));
+                else o = v;
+                X[m][4 * rg + q] = o;
+            }
+        }
+    }
+}
+
+// One MFMA layer: KB K blocks; bsel(kb) yields the B-operand register block of K block kb.
+// On entry the layer's first stage (aux + K block 0) has been issued into aux slot
+// `aux_slot` and chunk buffer PAR0.  NEXT_* describe the stage to issue while the last K block
+// computes (the next layer's first stage), 0/0 for none.
+template <int KB, int MB, int PAR0, int NEXT_AUX, int NEXT_CHUNK, bool FILM, class Init, class BSel>
+__device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film_layer, Init init, BSel bsel,
+                                             f32x16 (&acc)[8]) {
+    auto stage = [&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        constexpr int cur = (PAR0 + kb) & 1;
+        __syncthreads();
+        if constexpr (kb + 1 < KB) issue_stage<0, MB * 4, false>(c, 0, cur ^ 1, 0);
+        else issue_stage<NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot ^ 1, cur ^ 1, next_film_layer);
+        if constexpr (kb == 0) init(acc);
+        mma_chunk<MB>(c.smem + kLdsChunk0 + cur * kLdsChunk, c.lane, bsel(kbc), acc);
+    };
+    static_for<KB>(stage);
+}
+
+// forward flavour: accumulators start from the bias (+ the K=3 input columns) held in the layer's aux slot
+template <int KB, int MB, int PAR0, bool K3, int NEXT_AUX, int NEXT_CHUNK, bool FILM, class BSel>
+__device__ __forceinline__ void mma_layer(Ctx& c, int aux_slot, int next_film_layer, int k3_piece, float x, float y,
+                                          float z, BSel bsel, f32x16 (&acc)[8]) {
+    const auto init = [&](f32x16 (&a)[8]) {
+        init_acc<MB, K3>(c.smem + kLdsAux0 + aux_slot * kLdsAux, c.h, k3_piece, x, y, z, a);
+    };
+    mma_layer_fn<KB, MB, PAR0, NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot, next_film_layer, init, bsel, acc);
+}
+
+// acc = s * v[f] (v = VEC piece `piece` of an aux slot) or 0: starting values of the backward chain
+template <int MB>
+__device__ __forceinline__ void init_scaled_vec(const float* aux, int piece, int h, float s, f32x16 (&acc)[8]) {
+    const lds4_t p = lds_base(aux + h * 16);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 w = p[piece * 64 + m * 8 + rg];
+            acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
+        }
+}
+
+template <int MB>
+__device__ __forceinline__ void init_zero(f32x16 (&acc)[8]) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+}
+
+// sigma / rgb heads: dot products over the features a lane holds + one cross-half add.
+template <int MB>
+__device__ __forceinline__ float head_dot(const f32x16 (&X)[8], const float* aux, int piece, int h) {
+    const lds4_t p = lds_base(aux + h * 16);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 w = p[piece * 64 + m * 8 + rg];
+            s0 = fmaf(w.x, X[m][4 * rg + 0], s0);
+            s1 = fmaf(w.y, X[m][4 * rg + 1], s1);
+            s0 = fmaf(w.z, X[m][4 * rg + 2], s0);
+            s1 = fmaf(w.w, X[m][4 * rg + 3], s1);
+        }
+    float s = s0 + s1;
+    s += __shfl_xor(s, 32);
+    return s;
+}
+
+__device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
+
+// Positional-encoding blocks through an LDS scratch so sincosf is not inlined per register.
+// Feature f of the encoding of (x,y,z) with L frequencies: i=f/6, c=f%6: c<3 sin(2^i x_c) else cos(2^i x_{c-3}).
+template <int NBLK>
+__device__ __forceinline__ void posenc_blocks(float* scr, int lane, int h, float x, float y, float z, int nfeat,
+                                              f32x16* out) {
+#pragma unroll 1
+    for (int slot = 0; slot < NBLK * 16; ++slot) {
+        const int r = slot & 15, blk = slot >> 4;
+        const int f = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = 0.f;
+        if (f < nfeat) {
+            const int i = f / 6, cc = f - 6 * i;
+            const int comp = cc >= 3 ? cc - 3 : cc;
+            const float xv = comp == 0 ? x : (comp == 1 ? y : z);
+            const SinCos sc = fast_sincos(ldexpf(xv, i));
+            v = cc >= 3 ? sc.c : sc.s;
+        }
+        scr[slot * 64 + lane] = v;
+    }
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[blk][r] = scr[(blk * 16 + r) * 64 + lane];
+}
+
+struct PointIn {
+    float px, py, pz, dx, dy, dz;
+    int64_t p;      // global point index (row of the output)
+    bool valid;
+};
+
+// mode 0: x[M,6] points; mode 1: rays[N,2,3] + z[N,S].
+__device__ __forceinline__ PointIn load_point(int mode, const float* __restrict__ a, const float* __restrict__ zv,
+                                               int64_t group, int64_t ppg, int64_t rpg, int S, int64_t local) {
+    PointIn o;
+    o.valid = local < ppg;
+    const int64_t lc = o.valid ? local : ppg - 1;
+    o.p = group * ppg + lc;
+    if (mode == 0) {
+        const float* r = a + o.p * 6;
+        o.px = r[0]; o.py = r[1]; o.pz = r[2]; o.dx = r[3]; o.dy = r[4]; o.dz = r[5];
+    } else {
+        const int64_t ray = group * rpg + lc / S;
+        const float* r = a + ray * 6;
+        const float zz = zv[o.p];
+        const float d0 = r[3], d1 = r[4], d2 = r[5];
+        // render.py:134 pts = o + d*z (separate mul/add), :122 view = d / ||d||
+        o.px = __fadd_rn(r[0], __fmul_rn(d0, zz));
+        o.py = __fadd_rn(r[1], __fmul_rn(d1, zz));
+        o.pz = __fadd_rn(r[2], __fmul_rn(d2, zz));
+        const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)));
+        o.dx = d0 / nrm; o.dy = d1 / nrm; o.dz = d2 / nrm;
+    }
+    return o;
+}
+
+__device__ __forceinline__ Ctx make_ctx(float* smem, const MlpArgs& a, int64_t group) {
+    Ctx c;
+    c.smem = smem;
+    c.wp = a.packed;
+    c.film = a.film ? a.film + group * (kFilmLayers * kFilmRow) : nullptr;
+    c.lane = threadIdx.x & 63;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.h = c.lane >> 5;
+    return c;
+}
+
+__device__ __forceinline__ void store_out(const MlpArgs& a, const PointIn& pt, int h, float r, float g, float b,
+                                          float s) {
+    if (pt.valid && h == 0) reinterpret_cast<f32x4*>(a.out)[pt.p] = f32x4{r, g, b, s};
+}
+
+
+// ---- activations <-> HBM in [point][feature] row-major (training: saved layer inputs, gradients) --------
+// Register r of block m on lane (col j, half h) is feature 32m + 8(r>>2) + 4h + (r&3) of point j, so each
+// (m, rg) group of 4 registers is one aligned float4 of the point's row.
+template <int MB>
+__device__ __forceinline__ void store_rows(float* __restrict__ base, int64_t ld, int64_t p, bool valid, int h,
+                                           const f32x16 (&X)[8]) {
+    if (!valid) return;
+    f32x4* row = reinterpret_cast<f32x4*>(base + p * ld + 4 * h);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            row[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+}
+
+template <int MB>
+__device__ __forceinline__ void load_rows(const float* __restrict__ base, int64_t ld, int64_t p, int h,
+                                          f32x16 (&X)[8]) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(base + p * ld + 4 * h);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 t = row[m * 8 + rg * 2];
+            X[m][4 * rg + 0] = t.x; X[m][4 * rg + 1] = t.y; X[m][4 * rg + 2] = t.z; X[m][4 * rg + 3] = t.w;
+        }
+}
+
+}  // namespace mi

@@ -34,17 +34,27 @@ struct MlpArgs {
     int64_t tiles_per_group;
     int n_samples;
     int mode;
+    float* save;            // training: saved layer inputs, region r = save + act_offset(r) * save_points
+    int64_t save_points;    // points in this launch (row count of every saved region)
 };
 
 // host launchers (field_mlp.hip, render_stages.hip)
 int launch_pack(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream);
 int launch_mlp(int kind, const MlpArgs& a, int64_t n_groups, hipStream_t stream);
+int launch_pack_bwd(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream);
+int64_t train_acts_floats(int kind);
+int64_t train_grads_floats(int kind);
+int64_t bwd_partial_floats(int64_t P);
+int launch_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads, const float* raw,
+                          const float* g_raw, int64_t P, float* partial, float* const* gp, hipStream_t stream);
 int launch_gen_rays(int width, int height, double focal, const float* c2w, int64_t ray0, int64_t n, float* rays,
                     int compute_f64, hipStream_t stream);
 int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float* z_lin, const float* t_rand,
                          uint64_t seed, float* z, hipStream_t stream);
 int launch_composite(int64_t n, int S, const float* raw, const float* z, const float* rays, float* rgb, float* depth,
                      float* acc, float* weights, hipStream_t stream);
+int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,
+                         const float* g_depth, const float* g_acc, float* g_raw, hipStream_t stream);
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,
                        const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
                        hipStream_t stream);

@@ -146,6 +146,57 @@ __global__ __launch_bounds__(256) void composite_kernel(int64_t n, int S, const 
 }
 
 // ---------------------------------------------------------------------------------------
+// composite backward (autograd of raw_to_outputs, render.py:91-101): thread per ray, two sweeps.
+//   G_k = sum_c g_rgb[c]*(c_k[c]-1) + g_depth*z_k + g_acc        (dL/dw_k; rgb carries +1-acc)
+//   dL/dalpha_k = T_k * (G_k - S_k),  S_k = sum_{j>k} G_j alpha_j prod_{k<i<j} f_i
+//                 via the division-free recurrence S_k = G_{k+1} alpha_{k+1} + f_{k+1} S_{k+1}
+//   dL/dsigma_k = dL/dalpha_k * delta_k * (1-alpha_k);   dL/dc_k = g_rgb * w_k
+// f_k = 1-alpha_k+1e-10.  z and rays carry no gradient (z_samples is detached, render.py:141).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n, int S, const float* __restrict__ raw,
+                                                            const float* __restrict__ z,
+                                                            const float* __restrict__ rays,
+                                                            const float* __restrict__ g_rgb,
+                                                            const float* __restrict__ g_depth,
+                                                            const float* __restrict__ g_acc,
+                                                            float* __restrict__ g_raw) {
+    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n) return;
+    const float* rd = rays + ray * 6 + 3;
+    const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[ray] : 0.f, ga = g_acc ? g_acc[ray] : 0.f;
+    const float4* rw = reinterpret_cast<const float4*>(raw) + ray * S;
+    const float* zr = z + ray * S;
+    float4* out = reinterpret_cast<float4*>(g_raw) + ray * S;
+    // forward sweep: transmittance at every sample (kept in the output buffer's .w slot), fp64 product
+    double T = 1.0;
+    for (int k = 0; k < S; ++k) {
+        const float delta = (k + 1 < S ? zr[k + 1] - zr[k] : 1e10f) * nrm;
+        const float alpha = 1.0f - expf(-rw[k].w * delta);
+        out[k].w = (float)T;
+        T *= (double)((1.0f - alpha) + 1e-10f);
+    }
+    // reverse sweep
+    float Snext = 0.f;      // S_k for the sample being processed
+    for (int k = S - 1; k >= 0; --k) {
+        const float4 c = rw[k];
+        const float zk = zr[k];
+        const float delta = (k + 1 < S ? zr[k + 1] - zk : 1e10f) * nrm;
+        const float e = expf(-c.w * delta);
+        const float alpha = 1.0f - e;
+        const float f = (1.0f - alpha) + 1e-10f;
+        const float Tk = out[k].w;
+        const float w = alpha * Tk;
+        const float G = gr * (c.x - 1.f) + gg * (c.y - 1.f) + gb * (c.z - 1.f) + gd * zk + ga;
+        const float dalpha = Tk * (G - Snext);
+        out[k] = make_float4(gr * w, gg * w, gb * w, dalpha * delta * e);
+        Snext = G * alpha + f * Snext;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // sample_fine: one wave per ray.  bins = mids of the coarse linspace, w = weights[1:-1]+1e-5,
 // pdf = w/sum(w), cdf = [0, cumsum(pdf)] with the running sum in fp64 rounded per entry like
 // torch.cumsum on CPU; u = linspace(0,1,Nf); idx = #(cdf <= u) (searchsorted right=True); guarded lerp;
@@ -269,6 +320,14 @@ int launch_composite(int64_t n, int S, const float* raw, const float* z, const f
                            rays, rgb, depth, acc, weights);
     }
     return check_launch("composite");
+}
+
+int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,
+                         const float* g_depth, const float* g_acc, float* g_raw, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, S, raw, z,
+                       rays, g_rgb, g_depth, g_acc, g_raw);
+    return check_launch("composite_bwd");
 }
 
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,

@@ -40,6 +40,14 @@ SIGNATURES = {
     "mi_render_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
                               _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_composite_bwd": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_field_packed_bwd_floats": (_i64, [_int]),
+    "mi_field_pack_bwd": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),
+    "mi_field_train_acts_floats": (_i64, [_int]),
+    "mi_field_train_grads_floats": (_i64, [_int]),
+    "mi_field_bwd_partial_floats": (_i64, [_i64]),
+    "mi_field_eval_rays_train": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "mi_field_backward": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _i64, _vp, ctypes.POINTER(_vp), _int, _vp]),
     "mi_event_create": (_vp, []),
     "mi_event_destroy": (None, [_vp]),
     "mi_event_record": (_int, [_vp, _vp]),

@@ -85,7 +85,34 @@ class PackedField:
         n = lib.mi_field_packed_floats(kind)
         self.packed = torch.empty(n, dtype=torch.float32, device=self.device)
         self._versions = None
-        self._ptrs = None
+        self._versions_bwd = None
+        self.packed_bwd = None
+
+    def _sources(self):
+        srcs = []
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != self.device:
+                raise _lib.MiRenderError("field parameters must be fp32 on one device")
+            srcs.append(p.detach() if p.is_contiguous() else p.detach().contiguous())
+        return srcs
+
+    def refresh_bwd(self):
+        """Transposed weight stream for the backward chain (dX = W^T dA), same lazy refresh."""
+        vers = tuple((p.data_ptr(), p._version) for p in self.params)
+        if vers == self._versions_bwd:
+            return self.packed_bwd
+        lib = _lib.load()
+        if self.packed_bwd is None:
+            self.packed_bwd = torch.empty(lib.mi_field_packed_bwd_floats(self.kind), dtype=torch.float32,
+                                          device=self.device)
+        srcs = self._sources()
+        arr = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mi_field_pack_bwd(self.kind, arr, len(srcs), _lib.ptr(self.packed_bwd),
+                                             _lib.stream_ptr(self.device)), "mi_field_pack_bwd")
+        self._keep_bwd = srcs
+        self._versions_bwd = vers
+        return self.packed_bwd
 
     def refresh(self):
         vers = tuple((p.data_ptr(), p._version) for p in self.params)

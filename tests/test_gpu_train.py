@@ -1,0 +1,163 @@
+"""GPU: the training (backward) path against autograd of the CPU oracle and the golden gradient fixtures."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import fields as ofields, render_ref as R, synth  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def _nerf_render():
+    spec = importlib.util.spec_from_file_location(
+        "mi_nerf_render_t", os.path.join(ROOT, "msra-practice-project_amd", "nerf", "render.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def model(kind, sd):
+    from mirender import fields
+    m = {"nerf": fields.NeRF, "tiny_nerf": fields.TinyNeRF}[kind]()
+    m.load_state_dict(sd)
+    return m.to(dev())
+
+
+@pytest.mark.parametrize("S", [1, 13, 64, 192])
+def test_composite_bwd_vs_oracle_autograd(S):
+    from mirender import autograd as A
+    rng = np.random.Generator(np.random.PCG64(S))
+    n = 257
+    raw = rng.uniform(0, 1, size=(n, S, 4)).astype(np.float32)
+    raw[..., 3] = rng.exponential(2.0, size=(n, S)).astype(np.float32) * (rng.random((n, S)) < 0.5)
+    z = np.sort(rng.uniform(2, 6, size=(n, S)).astype(np.float32), -1)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    g = [torch.from_numpy(rng.normal(size=s).astype(np.float32)) for s in ((n, 3), (n,), (n,))]
+    rt = torch.from_numpy(raw).requires_grad_(True)
+    rgb, depth, acc, _ = R.composite(rt, torch.from_numpy(z), torch.from_numpy(rd))
+    (rgb * g[0]).sum().add((depth * g[1]).sum()).add((acc * g[2]).sum()).backward()
+    rays = torch.from_numpy(np.stack([np.zeros_like(rd), rd], 1)).to(dev())
+    got = A._composite_bwd(torch.from_numpy(raw).to(dev()), torch.from_numpy(z).to(dev()), rays,
+                           g[0].to(dev()), g[1].to(dev()), g[2].to(dev())).cpu()
+    scale = float(rt.grad.abs().max())
+    assert float((got - rt.grad).abs().max()) <= 2e-5 * max(1.0, scale)
+    # partial cotangents (None) behave as zeros
+    got2 = A._composite_bwd(torch.from_numpy(raw).to(dev()), torch.from_numpy(z).to(dev()), rays, g[0].to(dev()),
+                            None, None).cpu()
+    rt.grad = None
+    rgb, _, _, _ = R.composite(rt, torch.from_numpy(z), torch.from_numpy(rd))
+    (rgb * g[0]).sum().backward()
+    assert float((got2 - rt.grad).abs().max()) <= 2e-5 * max(1.0, float(rt.grad.abs().max()))
+
+
+def _grad_check(named_got, g, prefix, tol=2e-4):
+    """Fixture grads are stored as 512 strided samples + L2 norm per tensor (tests/golden/make_golden.py)."""
+    worst = 0.0
+    for name, t in named_got:
+        key = f"g.{prefix}{name}"
+        got = t.detach().cpu().numpy().reshape(-1)
+        scale = max(float(g[key + ".l2"]), 1e-12)
+        err = np.abs(got[g[key + ".idx"]] - g[key + ".val"]).max() / scale
+        nerr = abs(np.sqrt((got.astype(np.float64) ** 2).sum()) - float(g[key + ".l2"])) / scale
+        worst = max(worst, err, nerr)
+        assert err <= tol and nerr <= tol, (name, err, nerr)
+    return worst
+
+
+def test_nerf_loss_grads_golden(golden):
+    """Fixture F7: train_nerf.py:158-167 loss (use_alpha, fine model on) on a 48-ray batch, 64+128 samples;
+    gradients of every weight of both models from the reference's autograd."""
+    g = golden("nerf_grad_f7")
+    render = _nerf_render()
+    nc, nf = int(g["n_coarse"]), int(g["n_fine"])
+    cm = model("nerf", synth.state_dict("nerf", 50, True, 0.05))
+    fm = model("nerf", synth.state_dict("nerf", 51, True, 0.05))
+    out = render.render_rays(torch.from_numpy(g["rays"]).to(dev()), 2.0, 6.0, cm, fm, nc, nf,
+                             t_rand=torch.from_numpy(g["t_rand"]).to(dev()))
+    rgb_c, _, acc_c, rgb_f, _, acc_f = out
+    assert rgb_f.requires_grad
+    tgt = torch.from_numpy(g["target"]).to(dev())
+    loss = sum(torch.mean((rgb - tgt[:, :3]) ** 2) + 0.1 * torch.mean((acc - tgt[:, 3]) ** 2)
+               for rgb, acc in ((rgb_f, acc_f), (rgb_c, acc_c)))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-4
+    # coarse gradients do not depend on the ill-conditioned resampling: tight; fine: the fp32 oracle's
+    # resampled depths differ on a few rays, so the gate is looser (relative to each tensor's norm)
+    _grad_check([(k, p.grad) for k, p in cm.named_parameters()], g, "coarse.", tol=5e-4)
+    _grad_check([(k, p.grad) for k, p in fm.named_parameters()], g, "fine.", tol=2e-2)
+
+
+@pytest.mark.parametrize("kind,n,nc,nf,sharp", [("nerf", 37, 16, 24, True), ("tiny_nerf", 130, 8, 8, True),
+                                                 ("tiny_nerf", 130, 8, 8, False), ("nerf", 300, 12, 20, False)])
+def test_field_grads_vs_oracle_autograd_injected(kind, n, nc, nf, sharp):
+    """Same cotangents through the oracle (CPU autograd, fp32 and fp64) and through the HIP path with the
+    depths injected.  ReLU derivatives are 0/1 switches on the sign of a pre-activation, so any two fp32
+    pipelines disagree on a handful of (point, unit) pairs and each such flip moves a tensor's gradient by
+    ~1e-3 of its norm: the gate is the fp64 truth, with the fp32 oracle's own distance from it as the scale
+    (3x that, or 5e-3 of the tensor's norm, whichever is larger)."""
+    from mirender import autograd as A, fields, ops
+    sd_f = synth.state_dict(kind, 7, sharp, 0.05)
+    rays = torch.from_numpy(R.rays_from_camera(24, 24, 33.0, synth.pose_degrees(4.0, 15.0, -30.0))[100:100 + n])
+    rng = np.random.Generator(np.random.PCG64(1))
+    z = torch.from_numpy(np.sort(rng.uniform(2, 6, size=(n, nc + nf)).astype(np.float32), -1))
+    cot = [torch.from_numpy(rng.normal(size=s).astype(np.float32)) for s in ((n, 3), (n,), (n,))]
+    refs = {}
+    for dt in (torch.float32, torch.float64):
+        sd_req = {k: v.clone().to(dt).requires_grad_(True) for k, v in sd_f.items()}
+        f = ofields.make_field(kind, sd_req)
+        ro, rd = rays[:, 0].to(dt), rays[:, 1].to(dt)
+        raw = R.query_field(R.points_on_rays(ro, rd, z.to(dt)), rd / torch.norm(rd, dim=-1, keepdim=True), f)
+        rgb, depth, acc, _ = R.composite(raw, z.to(dt), rd)
+        ((rgb * cot[0].to(dt)).sum() + (depth * cot[1].to(dt)).sum() + (acc * cot[2].to(dt)).sum()).backward()
+        refs[dt] = {k: v.grad.double() for k, v in sd_req.items()}
+
+    m = model(kind, sd_f)
+    pf = fields.as_packed_field(m)
+    rays_d, z_d = rays.to(dev()), z.to(dev())
+    raw_d = ops.field_eval_rays(pf, rays_d, z_d)
+    g_raw = A._composite_bwd(raw_d, z_d, rays_d, *[c.to(dev()) for c in cot])
+    got = A._field_backward(pf, rays_d, z_d, raw_d, g_raw, None)
+    names = []
+    for key, _ in fields.SPECS[pf.kind]:
+        names += [key + ".weight", key + ".bias"]
+    tight = 0
+    for name, t in zip(names, got):
+        r64, r32 = refs[torch.float64][name], refs[torch.float32][name]
+        scale = max(float(r64.norm()), 1e-12)
+        e_hip = float((t.cpu().double() - r64).norm()) / scale
+        e_cpu = float((r32 - r64).norm()) / scale
+        assert e_hip <= max(5e-3, 3 * e_cpu), (name, e_hip, e_cpu)
+        tight += e_hip <= 3e-4
+    assert tight >= len(names) // 2          # most tensors see no flip at all and agree to fp32 rounding
+
+
+def test_shared_model_and_unused_outputs():
+    """coarse_model is fine_model (train_nerf.py:91,94 with use_fine_model false) and a loss on rgb_f only
+    (pi_GAN consumes only the fine rgb, pi_GAN/render.py:203): gradients flow once, coarse pass is skipped."""
+    render = _nerf_render()
+    sd = synth.state_dict("tiny_nerf", 3, True, 0.05)
+    m = model("tiny_nerf", sd)
+    rays = torch.from_numpy(R.rays_from_camera(16, 16, 22.0, synth.pose_degrees(4.0, 0.0, -30.0))).to(dev())
+    tr = synth.t_rand(256, 8, 1).to(dev())
+    out = render.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    out[3].sum().backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    assert all(torch.isfinite(g).all() for g in g1) and any(float(g.abs().max()) > 0 for g in g1)
+    for p in m.parameters():
+        p.grad = None
+    out = render.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    (out[3].sum() + out[0].sum()).backward()
+    g2 = [p.grad for p in m.parameters()]
+    assert any(float((a - b).abs().max()) > 0 for a, b in zip(g1, g2))     # coarse pass now contributes
+    with torch.no_grad():
+        out = render.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    assert not out[3].requires_grad
