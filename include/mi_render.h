@@ -146,12 +146,19 @@ int mi_field_eval_rays_train(int kind, const float* packed, const float* film, c
                              int64_t n_groups, int64_t rays_per_group, int n_samples, float* raw, float* acts,
                              void* stream);
 
-/* Backward of network(inputs) over `points` points: g_raw [points,4] = dL/d(raw) -> parameter gradients.
- * grad_params: HOST array of n_params device pointers (torch layouts, state-dict order), OVERWRITTEN.
- * grads_ws: [mi_field_train_grads_floats(kind) * points], partial_ws: mi_field_bwd_partial_floats(points). */
-int mi_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads_ws, const float* raw,
-                      const float* g_raw, int64_t points, float* partial_ws, float* const* grad_params,
-                      int n_params, void* stream);
+/* Backward of network(inputs) over n_groups*points_per_group points: g_raw [points,4] = dL/d(raw) ->
+ * parameter gradients (and, for FiLM kinds, the gradient of the FiLM table).
+ *   film            [n_groups,9,512] FiLM table of the forward (FiLM kinds) or NULL
+ *   grad_params     HOST array of n_params device pointers (torch layouts, state-dict order), OVERWRITTEN
+ *   grad_film       [n_groups,9,512] (FiLM kinds) or NULL, OVERWRITTEN
+ *   grads_ws        [mi_field_train_grads_floats(kind) * points]
+ *   partial_ws      [mi_field_bwd_partial_floats(points)]
+ *   film_partial_ws [mi_field_film_partial_floats(n_groups, points_per_group)] (FiLM kinds) or NULL */
+int64_t mi_field_film_partial_floats(int64_t n_groups, int64_t points_per_group);
+int mi_field_backward(int kind, const float* packed_bwd, const float* film, const float* acts, float* grads_ws,
+                      const float* raw, const float* g_raw, int64_t n_groups, int64_t points_per_group,
+                      float* partial_ws, float* film_partial_ws, float* const* grad_params, int n_params,
+                      float* grad_film, void* stream);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 

@@ -213,16 +213,21 @@ int mi_field_eval_rays_train(int kind, const float* packed, const float* film, c
                        raw, (hipStream_t)stream, acts);
 }
 
-int mi_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads_ws, const float* raw,
-                      const float* g_raw, int64_t points, float* partial_ws, float* const* grad_params,
-                      int n_params, void* stream) {
+int64_t mi_field_film_partial_floats(int64_t n_groups, int64_t points_per_group) {
+    return film_partial_floats(n_groups, points_per_group);
+}
+
+int mi_field_backward(int kind, const float* packed_bwd, const float* film, const float* acts, float* grads_ws,
+                      const float* raw, const float* g_raw, int64_t n_groups, int64_t points_per_group,
+                      float* partial_ws, float* film_partial_ws, float* const* grad_params, int n_params,
+                      float* grad_film, void* stream) {
     if (bad_kind(kind)) return MI_EINVAL;
     if (!packed_bwd || !acts || !grads_ws || !raw || !g_raw || !partial_ws || !grad_params ||
         n_params != 2 * kNumLayers[kind]) { set_error("mi_field_backward: bad arguments"); return MI_EINVAL; }
     for (int i = 0; i < n_params; ++i)
         if (!grad_params[i]) { set_error("gradient pointer %d is null", i); return MI_EINVAL; }
-    return launch_field_backward(kind, packed_bwd, acts, grads_ws, raw, g_raw, points, partial_ws, grad_params,
-                                 (hipStream_t)stream);
+    return launch_field_backward(kind, packed_bwd, acts, grads_ws, raw, g_raw, n_groups, points_per_group, film,
+                                 film_partial_ws, grad_film, partial_ws, grad_params, (hipStream_t)stream);
 }
 
 void* mi_event_create(void) {

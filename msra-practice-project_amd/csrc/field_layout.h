@@ -225,6 +225,23 @@ constexpr RegionLayout nerf_grads() { return {11, {256, 256, 256, 256, 256, 256,
 constexpr RegionLayout tiny_acts() { return {7, {64, 256, 256, 256, 256, 32, 128}}; }
 constexpr RegionLayout tiny_grads() { return {6, {256, 256, 256, 256, 128, 4}}; }
 
+// SirenNeRF acts: 0 xin(8: xyz, dir, 0, 0) | layer l=1..8: 2l-1 X_l = sin(30 A_{l-1}), 2l C_l = 30 cos(30 A_{l-1}) |
+//                 17 G (layers_dir.0 out) | 18 X_d (128) | 19 C_d (128).   grads: as NeRF.
+constexpr RegionLayout siren_acts() {
+    return {20, {8, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 128}};
+}
+constexpr RegionLayout siren_grads() { return nerf_grads(); }
+// FilmSirenNeRF acts: 0 xin(8) | FiLM layer l=0..8 (input, hidden 0..6, rgb hidden): 1+3l A_l (linear out),
+//                     2+3l X_l = sin(30 u), 3+3l C_l = 30 cos(30 u), u = gamma*A + beta.
+// grads: 0..8 dA_l (256) | 9 head pre-act grads (4)
+constexpr RegionLayout film_acts() {
+    RegionLayout L{28, {}};
+    L.width[0] = 8;
+    for (int i = 1; i < 28; ++i) L.width[i] = 256;
+    return L;
+}
+constexpr RegionLayout film_grads() { return {10, {256, 256, 256, 256, 256, 256, 256, 256, 256, 4}}; }
+
 constexpr int packed_floats(const PackTable& t) {
     const PackItem& last = t.item[t.n_items - 1];
     return t.dst_off[t.n_items - 1] + (last.type == ITEM_CHUNK ? last.mb * 1024 : kPiece);

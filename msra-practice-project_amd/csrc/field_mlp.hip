@@ -204,6 +204,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
 // =========================================================================================
 // SirenNeRF (nerf/nerf.py:153-170): sin(30 * linear) layers on raw xyz / dir
 // =========================================================================================
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t group = blockIdx.x / a.tiles_per_group;
@@ -215,25 +216,43 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
                                   tile * 128 + c.wave * 32 + (c.lane & 31));
     f32x16 X[8], acc[8];
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
+    constexpr RegionLayout RL = siren_acts();
+    const int64_t SP = a.save_points;
+    const auto region = [&](int idx) { return a.save + (int64_t)region_offset(RL, idx) * SP; };
+    // sin layer l (1..8): X_l -> region 2l-1, C_l -> region 2l
+    const auto sin_act = [&](int l) {
+        if constexpr (SAVE)
+            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, nullptr, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
+                                         a.save + (int64_t)(8 + 512 * (l - 1) + 256) * SP, 256, pt.p, pt.valid);
+        else
+            activate<8, ACT_SIN30>(acc, X, nullptr, c.h);
+    };
+    if constexpr (SAVE) {
+        if (pt.valid && c.h == 0) {
+            f32x4* xin = reinterpret_cast<f32x4*>(a.save + pt.p * 8);
+            xin[0] = f32x4{pt.px, pt.py, pt.pz, pt.dx};
+            xin[1] = f32x4{pt.dy, pt.dz, 0.f, 0.f};
+        }
+    }
 
     int slot = 0;
     __syncthreads();
     issue_stage<1, 32, false>(c, 1, 0, 0);
     init_acc<8, true>(smem + kLdsAux0, c.h, 1, pt.px, pt.py, pt.pz, acc);
-    activate<8, ACT_SIN30>(acc, X, nullptr, c.h); slot ^= 1;
+    sin_act(1); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
         mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        activate<8, ACT_SIN30>(acc, X, nullptr, c.h); slot ^= 1;
+        sin_act(l + 1); slot ^= 1;
     }
     mma_layer<8, 8, 0, false, 4, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // layers_pos[4]
-    activate<8, ACT_SIN30>(acc, X, nullptr, c.h); slot ^= 1;
+    sin_act(5); slot ^= 1;
     mma_layer<8, 8, 0, true, 1, 32, false>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc);  // [5]: [pos | h]
-    activate<8, ACT_SIN30>(acc, X, nullptr, c.h); slot ^= 1;
+    sin_act(6); slot ^= 1;
     mma_layer<8, 8, 0, false, 3, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // [6]
-    activate<8, ACT_SIN30>(acc, X, nullptr, c.h); slot ^= 1;
+    sin_act(7); slot ^= 1;
     mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // [7] + sigma head
-    activate<8, ACT_SIN30>(acc, X, nullptr, c.h);
+    sin_act(8);
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
@@ -242,8 +261,12 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     slot ^= 1;
     mma_layer<8, 8, 0, false, 8, 16, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // layers_dir[0] linear
     activate<8, ACT_LINEAR>(acc, X, nullptr, c.h); slot ^= 1;
+    if constexpr (SAVE) store_rows<8>(region(17), 256, pt.p, pt.valid, c.h, X);             // G
     mma_layer<8, 4, 0, true, 0, 0, false>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc);   // layers_dir[1]: [h | dir]
-    activate<4, ACT_SIN30>(acc, X, nullptr, c.h);
+    if constexpr (SAVE)
+        activate_train<4, ACT_SIN30>(acc, X, nullptr, c.h, nullptr, region(18), region(19), 128, pt.p, pt.valid);
+    else
+        activate<4, ACT_SIN30>(acc, X, nullptr, c.h);
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 4, c.h) + aux[7 * kPiece + 0]);
     const float g = sigmoidf(head_dot<4>(X, aux, 5, c.h) + aux[7 * kPiece + 1]);
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
 // FilmSirenNeRF (pi_GAN/modules.py:101-118): sin(30 * (gamma * linear + beta)), one FiLM
 // table per group (image)
 // =========================================================================================
-template <bool USE_DIR>
+template <bool USE_DIR, bool SAVE>
 __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int64_t group = blockIdx.x / a.tiles_per_group;
@@ -268,21 +291,39 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     f32x16 X[8], acc[8];
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto film_row = [&](int s) { return smem + kLdsFilm0 + s * kFilmRow; };
+    const int64_t SP = a.save_points;
+    // FiLM layer l (0..8): A_l -> region 1+3l, X_l -> 2+3l, C_l -> 3+3l (each 256 wide, after the 8-wide xin)
+    const auto film_act = [&](int l, int slot_) {
+        if constexpr (SAVE) {
+            float* base = a.save + (int64_t)(8 + 768 * l) * SP;
+            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, base, base + 256 * SP, base + 512 * SP, 256, pt.p,
+                                        pt.valid);
+        } else {
+            activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h);
+        }
+    };
+    if constexpr (SAVE) {
+        if (pt.valid && c.h == 0) {
+            f32x4* xin = reinterpret_cast<f32x4*>(a.save + pt.p * 8);
+            xin[0] = f32x4{pt.px, pt.py, pt.pz, pt.dx};
+            xin[1] = f32x4{pt.dy, pt.dz, 0.f, 0.f};
+        }
+    }
 
     int slot = 0;
     __syncthreads();
     issue_stage<1, 32, true>(c, 1, 0, 1);
     init_acc<8, true>(smem + kLdsAux0, c.h, 1, pt.px, pt.py, pt.pz, acc);
-    activate<8, ACT_FILM>(acc, X, film_row(0), c.h); slot ^= 1;
+    film_act(0, 0); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 5; ++l) {                                                   // hidden_layers[0..4]
         mma_layer<8, 8, 0, false, 1, 32, true>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        activate<8, ACT_FILM>(acc, X, film_row(slot), c.h); slot ^= 1;
+        film_act(l, slot); slot ^= 1;
     }
     mma_layer<8, 8, 0, false, 3, 32, true>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc);  // hidden_layers[5]
-    activate<8, ACT_FILM>(acc, X, film_row(slot), c.h); slot ^= 1;
+    film_act(6, slot); slot ^= 1;
     mma_layer<8, 8, 0, false, USE_DIR ? 8 : 5, 32, true>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc);  // hidden_layers[6]
-    activate<8, ACT_FILM>(acc, X, film_row(slot), c.h);
+    film_act(7, slot);
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
@@ -290,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     }
     slot ^= 1;
     mma_layer<8, 8, 0, USE_DIR, 0, 0, false>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc);   // hidden_layer_rgb
-    activate<8, ACT_FILM>(acc, X, film_row(slot), c.h);
+    film_act(8, slot);
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     constexpr int hp = USE_DIR ? 4 : 1;
     const float r = sigmoidf(head_dot<8>(X, aux, hp + 0, c.h) + aux[(hp + 3) * kPiece + 0]);
@@ -317,30 +358,28 @@ int launch_mlp(int kind, const MlpArgs& a, int64_t n_groups, hipStream_t stream)
     // 84 KiB of dynamic LDS: raise the per-kernel limit once (host-side attribute, no device work)
     static bool attr_done = false;
     if (!attr_done) {
-        const void* fns[] = {(const void*)nerf_fwd_kernel<false, false>, (const void*)siren_fwd_kernel,
-                             (const void*)film_fwd_kernel<true>, (const void*)film_fwd_kernel<false>,
-                             (const void*)nerf_fwd_kernel<true, false>, (const void*)nerf_fwd_kernel<false, true>,
-                             (const void*)nerf_fwd_kernel<true, true>};
+        const void* fns[] = {(const void*)nerf_fwd_kernel<false, false>, (const void*)nerf_fwd_kernel<false, true>,
+                             (const void*)nerf_fwd_kernel<true, false>, (const void*)nerf_fwd_kernel<true, true>,
+                             (const void*)siren_fwd_kernel<false>, (const void*)siren_fwd_kernel<true>,
+                             (const void*)film_fwd_kernel<true, false>, (const void*)film_fwd_kernel<true, true>,
+                             (const void*)film_fwd_kernel<false, false>, (const void*)film_fwd_kernel<false, true>};
         for (const void* f : fns) {
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         }
         attr_done = true;
     }
+    const bool sv = a.save != nullptr;
+#define MI_LAUNCH(K) hipLaunchKernelGGL((K), grid, block, lds, stream, a)
     switch (kind) {
-        case 0:
-            if (a.save) hipLaunchKernelGGL((nerf_fwd_kernel<false, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((nerf_fwd_kernel<false, false>), grid, block, lds, stream, a);
-            break;
-        case 1: hipLaunchKernelGGL(siren_fwd_kernel, grid, block, lds, stream, a); break;
-        case 2: hipLaunchKernelGGL(film_fwd_kernel<true>, grid, block, lds, stream, a); break;
-        case 3: hipLaunchKernelGGL(film_fwd_kernel<false>, grid, block, lds, stream, a); break;
-        case 4:
-            if (a.save) hipLaunchKernelGGL((nerf_fwd_kernel<true, true>), grid, block, lds, stream, a);
-            else hipLaunchKernelGGL((nerf_fwd_kernel<true, false>), grid, block, lds, stream, a);
-            break;
+        case 0: if (sv) MI_LAUNCH((nerf_fwd_kernel<false, true>)); else MI_LAUNCH((nerf_fwd_kernel<false, false>)); break;
+        case 1: if (sv) MI_LAUNCH((siren_fwd_kernel<true>)); else MI_LAUNCH((siren_fwd_kernel<false>)); break;
+        case 2: if (sv) MI_LAUNCH((film_fwd_kernel<true, true>)); else MI_LAUNCH((film_fwd_kernel<true, false>)); break;
+        case 3: if (sv) MI_LAUNCH((film_fwd_kernel<false, true>)); else MI_LAUNCH((film_fwd_kernel<false, false>)); break;
+        case 4: if (sv) MI_LAUNCH((nerf_fwd_kernel<true, true>)); else MI_LAUNCH((nerf_fwd_kernel<true, false>)); break;
         default: set_error("unknown field kind %d", kind); return -1;
     }
+#undef MI_LAUNCH
     return check_launch("field_mlp_fwd");
 }
 

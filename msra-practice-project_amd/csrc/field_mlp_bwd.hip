@@ -89,6 +89,11 @@ struct BwdArgs {
     const float* raw;        // [P,4] forward outputs (rgb post-sigmoid, sigma post-ReLU)
     const float* g_raw;      // [P,4] dL/d(raw)
     int64_t points;
+    // FiLM kinds: one table per group of points_per_group consecutive points; per-tile partial sums of
+    // d gamma | d beta go to film_partial[layer][tile][wave][512]
+    const float* film;
+    float* film_partial;
+    int64_t points_per_group, tiles_per_group, n_tiles;
 };
 
 // dA = dX (.) relu'(H) with H the saved post-ReLU activation; stores dA rows and leaves them in X.
@@ -202,6 +207,206 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     }
 }
 
+// dA = dX (.) C with C = 30 cos(30 A) saved by the training forward; stores dA rows, leaves them in X.
+template <int MB>
+__device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ C,
+                                              float* __restrict__ dA, int64_t ld, int64_t p, bool valid, int h) {
+    const f32x4* crow = reinterpret_cast<const f32x4*>(C + p * ld + 4 * h);
+    f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 cv = crow[m * 8 + rg * 2];
+            f32x4 o;
+            o.x = cv.x * dX[m][4 * rg + 0]; o.y = cv.y * dX[m][4 * rg + 1];
+            o.z = cv.z * dX[m][4 * rg + 2]; o.w = cv.w * dX[m][4 * rg + 3];
+            X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
+            if (valid) drow[m * 8 + rg * 2] = o;
+        }
+}
+
+// =========================================================================================
+// SirenNeRF backward chain (reverse of nerf/nerf.py:153-170); same shape as NeRF's, sin derivatives
+// =========================================================================================
+__global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Ctx c;
+    c.smem = smem; c.wp = a.packed; c.film = nullptr;
+    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.h = c.lane >> 5;
+    constexpr RegionLayout AL = siren_acts();
+    constexpr RegionLayout GL = siren_grads();
+    const int64_t P = a.points;
+    issue_stage<3, 32, false>(c, 0, 0, 0);
+
+    const int64_t local = (int64_t)blockIdx.x * 128 + c.wave * 32 + (c.lane & 31);
+    const bool valid = local < P;
+    const int64_t p = valid ? local : P - 1;
+    const f32x4 g = reinterpret_cast<const f32x4*>(a.g_raw)[p];
+    const f32x4 o = reinterpret_cast<const f32x4*>(a.raw)[p];
+    const float d0 = g.x * o.x * (1.f - o.x), d1 = g.y * o.y * (1.f - o.y), d2 = g.z * o.z * (1.f - o.z);
+    const float ds = o.w > 0.f ? g.w : 0.f;
+    if (valid && c.h == 0)
+        reinterpret_cast<f32x4*>(a.grads + (int64_t)region_offset(GL, GL.n - 1) * P)[p] = f32x4{d0, d1, d2, ds};
+
+    f32x16 X[8], acc[8];
+    const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
+    const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
+    const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
+    const auto zero = [&](f32x16 (&x)[8]) { init_zero<8>(x); };
+
+    __syncthreads();
+    {   // dX_d = W_rgb^T d_pre_rgb (128 features)
+        const lds4_t pw = lds_base(smem + kLdsAux0 + c.h * 16);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 w0 = pw[0 * 64 + m * 8 + rg], w1 = pw[1 * 64 + m * 8 + rg], w2 = pw[2 * 64 + m * 8 + rg];
+                acc[m][4 * rg + 0] = fmaf(w2.x, d2, fmaf(w1.x, d1, w0.x * d0));
+                acc[m][4 * rg + 1] = fmaf(w2.y, d2, fmaf(w1.y, d1, w0.y * d0));
+                acc[m][4 * rg + 2] = fmaf(w2.z, d2, fmaf(w1.z, d1, w0.z * d0));
+                acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
+            }
+    }
+    sin_bwd_store<4>(acc, X, acts(19), grads(9), 128, p, valid, c.h);                          // dA layers_dir.1
+    int slot = 0;
+    mma_layer_fn<4, 8, 0, 1, 32, false>(c, slot, 0, zero, sel_x, acc);                          // layers_dir.1^T (h part)
+    slot ^= 1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) X[m] = acc[m];                                                  // layers_dir.0 is linear
+    store_rows<8>(grads(8), 256, p, valid, c.h, X);
+    mma_layer_fn<8, 8, 0, 0, 32, false>(
+        c, slot, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0 + slot * kLdsAux, 0, c.h, ds, x); }, sel_x,
+        acc);                                                                                   // layers_dir.0^T + sigma head
+    sin_bwd_store<8>(acc, X, acts(16), grads(7), 256, p, valid, c.h);                          // dA7 = dX8 (.) C8
+#pragma unroll 1
+    for (int l = 7; l >= 2; --l) {                                                              // L7^T .. L2^T
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, zero, sel_x, acc);
+        sin_bwd_store<8>(acc, X, a.acts + (int64_t)(8 + 512 * (l - 1) + 256) * P, a.grads + (int64_t)(256 * (l - 1)) * P,
+                         256, p, valid, c.h);                                                   // dA_{l-1} = dX_l (.) C_l
+    }
+    mma_layer_fn<8, 8, 0, 0, 0, false>(c, slot, 0, zero, sel_x, acc);                           // L1^T
+    sin_bwd_store<8>(acc, X, acts(2), grads(0), 256, p, valid, c.h);                           // dA0 = dX1 (.) C1
+}
+
+// =========================================================================================
+// FilmSirenNeRF backward chain (reverse of pi_GAN/modules.py:101-118).  Layer l: A = W x + b,
+// u = gamma A + beta, X = sin(30 u).  dL/du = dX (.) C;  d gamma = sum_p dL/du * A;  d beta = sum_p dL/du;
+// dA = dL/du * gamma.  The per-tile sums over the 32 points of each wave go to film_partial.
+// =========================================================================================
+template <int MB>
+__device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ A,
+                                               const float* __restrict__ C, const float* __restrict__ gamma,
+                                               float* __restrict__ dA, float* __restrict__ part, int64_t p, bool valid,
+                                               int lane, int h) {
+    const f32x4* arow = reinterpret_cast<const f32x4*>(A + p * 256 + 4 * h);
+    const f32x4* crow = reinterpret_cast<const f32x4*>(C + p * 256 + 4 * h);
+    const f32x4* grow = reinterpret_cast<const f32x4*>(gamma + 4 * h);
+    f32x4* drow = reinterpret_cast<f32x4*>(dA + p * 256 + 4 * h);
+    const float live = valid ? 1.f : 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 av = arow[m * 8 + rg * 2], cv = crow[m * 8 + rg * 2], gv = grow[m * 8 + rg * 2];
+            f32x4 du, o, sg, sb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                du[q] = cv[q] * dX[m][4 * rg + q] * live;
+                o[q] = du[q] * gv[q];
+                X[m][4 * rg + q] = o[q];
+                sg[q] = du[q] * av[q];
+                sb[q] = du[q];
+            }
+            if (valid) drow[m * 8 + rg * 2] = o;
+            // sum over the 32 points of this lane half
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sg[q] += __shfl_xor(sg[q], off);
+                    sb[q] += __shfl_xor(sb[q], off);
+                }
+            if ((lane & 31) == 0) {
+                *reinterpret_cast<f32x4*>(part + 32 * m + 8 * rg + 4 * h) = sg;
+                *reinterpret_cast<f32x4*>(part + 256 + 32 * m + 8 * rg + 4 * h) = sb;
+            }
+        }
+}
+
+template <bool USE_DIR>
+__global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    Ctx c;
+    c.smem = smem; c.wp = a.packed; c.film = nullptr;
+    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.h = c.lane >> 5;
+    const int64_t P = a.points;
+    issue_stage<4, 32, false>(c, 0, 0, 0);                 // rgb head rows x3, sigma row; K block 0 of hidden_layer_rgb^T
+
+    const int64_t group = blockIdx.x / a.tiles_per_group;
+    const int64_t tile = blockIdx.x % a.tiles_per_group;
+    const int64_t local = tile * 128 + c.wave * 32 + (c.lane & 31);
+    const bool valid = local < a.points_per_group;
+    const int64_t p = group * a.points_per_group + (valid ? local : a.points_per_group - 1);
+    const float* film = a.film + group * (kFilmLayers * kFilmRow);
+    const f32x4 g = reinterpret_cast<const f32x4*>(a.g_raw)[p];
+    const f32x4 o = reinterpret_cast<const f32x4*>(a.raw)[p];
+    const float d0 = g.x * o.x * (1.f - o.x), d1 = g.y * o.y * (1.f - o.y), d2 = g.z * o.z * (1.f - o.z);
+    const float ds = o.w > 0.f ? g.w : 0.f;
+    if (valid && c.h == 0) reinterpret_cast<f32x4*>(a.grads + (int64_t)(9 * 256) * P)[p] = f32x4{d0, d1, d2, ds};
+
+    f32x16 X[8], acc[8];
+    const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
+    const auto zero = [&](f32x16 (&x)[8]) { init_zero<8>(x); };
+    // FiLM layer l: A at acts region 1+3l, C at 3+3l; dA at grads region l; partial row (l, tile, wave)
+    const auto layer_bwd = [&](int l) {
+        const float* base = a.acts + (int64_t)(8 + 768 * l) * P;
+        float* part = a.film_partial + (((int64_t)l * a.n_tiles + blockIdx.x) * 4 + c.wave) * 512;
+        film_bwd_store<8>(acc, X, base, base + 512 * P, film + l * kFilmRow, a.grads + (int64_t)(256 * l) * P, part, p,
+                          valid, c.lane, c.h);
+    };
+
+    __syncthreads();
+    {   // dX_8 = W_rgb^T d_pre_rgb (256 features)
+        const lds4_t pw = lds_base(smem + kLdsAux0 + c.h * 16);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 w0 = pw[0 * 64 + m * 8 + rg], w1 = pw[1 * 64 + m * 8 + rg], w2 = pw[2 * 64 + m * 8 + rg];
+                acc[m][4 * rg + 0] = fmaf(w2.x, d2, fmaf(w1.x, d1, w0.x * d0));
+                acc[m][4 * rg + 1] = fmaf(w2.y, d2, fmaf(w1.y, d1, w0.y * d0));
+                acc[m][4 * rg + 2] = fmaf(w2.z, d2, fmaf(w1.z, d1, w0.z * d0));
+                acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
+            }
+    }
+    layer_bwd(8);                                                                               // hidden_layer_rgb
+    mma_layer_fn<8, 8, 0, 0, 32, false>(
+        c, 0, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0, 3, c.h, ds, x); }, sel_x, acc);
+#pragma unroll 1
+    for (int l = 7; l >= 2; --l) {                                                              // hidden_layers[6..1]
+        layer_bwd(l);
+        mma_layer_fn<8, 8, 0, 0, 32, false>(c, 0, 0, zero, sel_x, acc);
+    }
+    layer_bwd(1);                                                                               // hidden_layers[0]
+    mma_layer_fn<8, 8, 0, 0, 0, false>(c, 0, 0, zero, sel_x, acc);
+    layer_bwd(0);                                                                               // input_layer
+}
+
+// d film[g][l][0:256] = sum over the group's tiles and waves of the gamma partials, [256:512] the beta ones
+__global__ void film_reduce_kernel(const float* __restrict__ part, int64_t n_tiles, int64_t tiles_per_group,
+                                   float* __restrict__ dfilm) {
+    const int l = blockIdx.y;
+    const int64_t g = blockIdx.x;
+    for (int f = threadIdx.x; f < 512; f += blockDim.x) {
+        float s = 0.f;
+        const float* src = part + (((int64_t)l * n_tiles + g * tiles_per_group) * 4) * 512 + f;
+        for (int64_t t = 0; t < tiles_per_group * 4; ++t) s += src[t * 512];
+        dfilm[(g * kFilmLayers + l) * kFilmRow + f] = s;
+    }
+}
+
 // =========================================================================================
 // dW GEMM over points.  A side: dA[p][a_col0 + 128*wm + 4*i + c], B side: X[p][x_col0 + 32*CB*wk + CB*j + d].
 // acc[c][d] (+)= A_c (x) B_d per point pair.  Workgroup = 4 waves = tiles (WM x WK) x k-split.
@@ -278,6 +483,30 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
     }
 }
 
+// Cross-slab reduction, deterministic (fixed order), two levels so it streams at HBM rate:
+// level 1 sums groups of kReduceGroup partial tiles into tmp (grid.y = groups, float4 per thread, 4 loads in
+// flight); level 2 sums the groups into the gradient tensor with its row/column validity and placement.
+constexpr int kReduceGroup = 16;
+
+__global__ __launch_bounds__(256) void reduce_level1_kernel(const float* __restrict__ partial, int n_partials,
+                                                            int tile_floats, float* __restrict__ tmp) {
+    const int idx4 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx4 * 4 >= tile_floats) return;
+    const int k0 = blockIdx.y * kReduceGroup;
+    const int k1 = k0 + kReduceGroup < n_partials ? k0 + kReduceGroup : n_partials;
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial) + idx4;
+    const int64_t stride4 = tile_floats / 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        const f32x4 a = src[(int64_t)k * stride4], b = src[(int64_t)(k + 1) * stride4];
+        const f32x4 c = src[(int64_t)(k + 2) * stride4], d = src[(int64_t)(k + 3) * stride4];
+        s += a; s += b; s += c; s += d;
+    }
+    for (; k < k1; ++k) s += src[(int64_t)k * stride4];
+    reinterpret_cast<f32x4*>(tmp)[(int64_t)blockIdx.y * stride4 + idx4] = s;
+}
+
 // dst[row][dst_col0 + col] = sum over partials (fixed order), rows < rows_valid, cols < cols_valid
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int n_partials, int TM, int TK,
                                        float* __restrict__ dst, int dst_ld, int dst_col0, int rows_valid,
@@ -291,9 +520,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int n_
     dst[(int64_t)row * dst_ld + dst_col0 + col] = s;
 }
 
-// head weight gradients: dW[c][f] = sum_p dpre[p][c0+c] * H[p][f] (c < NC <= 3), db[c] = sum_p dpre[p][c0+c].
-// grid = slabs, block = 256 threads = features.  partial[slab][4][256] (+ bias in row 3's unused... separate buf)
-__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ dpre, int c0, int nc,
+// Thin gradients: out[c][f] = sum_p S[p][c0+c] * H[p][f] for c < nc <= 3, f < F <= 256, plus sum_p S[p][c0+c].
+//   heads:        S = head pre-activation grads [P,4], H = the head's input  -> dW_head[c][f], db_head[c]
+//   K = 3 inputs: S = xin [P,8] (xyz | dir),           H = dA of the layer   -> dW[f][col0 + c]
+// grid = point slabs, block = 256 threads = features; partial[slab][4][256], bias_partial[slab][4].
+__global__ __launch_bounds__(256) void thin_grad_kernel(const float* __restrict__ S, int lds_, int c0, int nc,
                                                         const float* __restrict__ H, int ldh, int F, int64_t P,
                                                         int slab_pts, float* __restrict__ partial,
                                                         float* __restrict__ bias_partial) {
@@ -302,18 +533,29 @@ __global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict_
     const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     for (int64_t p = p0; p < p1; ++p) {
-        const float4 d = reinterpret_cast<const float4*>(dpre)[p];
-        const float dv[4] = {d.x, d.y, d.z, d.w};
+        const float* sp = S + p * lds_ + c0;
+        const float s0 = sp[0], s1 = nc > 1 ? sp[1] : 0.f, s2 = nc > 2 ? sp[2] : 0.f;
         const float hv = f < F ? H[p * ldh + f] : 0.f;
-        a0 = fmaf(dv[c0], hv, a0); b0 += dv[c0];
-        if (nc > 1) { a1 = fmaf(dv[c0 + 1], hv, a1); b1 += dv[c0 + 1]; }
-        if (nc > 2) { a2 = fmaf(dv[c0 + 2], hv, a2); b2 += dv[c0 + 2]; }
+        a0 = fmaf(s0, hv, a0); a1 = fmaf(s1, hv, a1); a2 = fmaf(s2, hv, a2);
+        b0 += s0; b1 += s1; b2 += s2;
     }
     float* out = partial + (int64_t)blockIdx.x * 4 * 256;
     out[0 * 256 + f] = a0; out[1 * 256 + f] = a1; out[2 * 256 + f] = a2; out[3 * 256 + f] = 0.f;
     if (f == 0) {
         float* bo = bias_partial + (int64_t)blockIdx.x * 4;
         bo[0] = b0; bo[1] = b1; bo[2] = b2; bo[3] = 0.f;
+    }
+}
+
+// dst[f*ld + col0 + c] = sum_k partial[k][c][f]   (K = 3 weight columns)
+__global__ void reduce_columns_kernel(const float* __restrict__ partial, int n, int nc, int F, float* __restrict__ dst,
+                                      int ld, int col0) {
+    const int f = threadIdx.x;
+    if (f >= F) return;
+    for (int c = 0; c < nc; ++c) {
+        float s = 0.f;
+        for (int k = 0; k < n; ++k) s += partial[((int64_t)k * 4 + c) * 256 + f];
+        dst[(int64_t)f * ld + col0 + c] = s;
     }
 }
 
@@ -329,6 +571,8 @@ int launch_pack_bwd(int kind, const float* const* params, int n_params, float* p
 int64_t train_acts_floats(int kind) {
     switch (kind) {
         case 0: return region_total(nerf_acts());
+        case 1: return region_total(siren_acts());
+        case 2: case 3: return region_total(film_acts());
         case 4: return region_total(tiny_acts());
     }
     return -1;
@@ -336,22 +580,44 @@ int64_t train_acts_floats(int kind) {
 int64_t train_grads_floats(int kind) {
     switch (kind) {
         case 0: return region_total(nerf_grads());
+        case 1: return region_total(siren_grads());
+        case 2: case 3: return region_total(film_grads());
         case 4: return region_total(tiny_grads());
     }
     return -1;
 }
+// per-tile FiLM partial sums: [9 layers][tiles][4 waves][512]
+int64_t film_partial_floats(int64_t n_groups, int64_t points_per_group) {
+    return (int64_t)kFilmLayers * n_groups * ((points_per_group + 127) / 128) * 4 * 512;
+}
 
 static int slab_points(int64_t P) {
-    int64_t s = (P + 511) / 512;           // aim at >= 512 workgroups
+    int64_t s = (P + 511) / 512;           // aim at ~512 workgroups (2 per CU)
     s = (s + 31) / 32 * 32;
     if (s < 256) s = 256;
-    if (s > 4096) s = 4096;
     return (int)s;
 }
 int64_t bwd_partial_floats(int64_t P) {
     const int slab = slab_points(P);
     const int64_t slabs = (P + slab - 1) / slab;
-    return slabs * 4 * (256 * 256 + 256);  // up to 4 k-split partial tiles + bias rows per slab
+    const int64_t tiles = slabs * 4;                                   // up to 4 k-split partial tiles per slab
+    const int64_t groups = (tiles + kReduceGroup - 1) / kReduceGroup;
+    return (tiles + groups) * (256 * 256) + tiles * 256 + 1024;        // partial tiles + level-1 sums + bias rows
+}
+
+// Sum `n` partial tiles of TM x TK (at `partial`, level-1 scratch at `tmp`) into dst.
+static void reduce_tiles(const float* partial, int n, int TM, int TK, float* tmp, float* dst, int dst_ld, int dst_col0,
+                         int rows_valid, int cols_valid, hipStream_t stream) {
+    const int tile = TM * TK;
+    if (n > kReduceGroup && tile % 4 == 0) {
+        const int groups = (n + kReduceGroup - 1) / kReduceGroup;
+        hipLaunchKernelGGL(reduce_level1_kernel, dim3((tile / 4 + 255) / 256, groups), dim3(256), 0, stream, partial, n,
+                           tile, tmp);
+        partial = tmp;
+        n = groups;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((tile + 255) / 256), dim3(256), 0, stream, partial, n, TM, TK, dst,
+                       dst_ld, dst_col0, rows_valid, cols_valid);
 }
 
 struct GemmJob {
@@ -367,14 +633,13 @@ static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P
     constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
     const int slab = slab_points(P);
     const int slabs = (int)((P + slab - 1) / slab);
-    float* bias_partial = partial + (int64_t)slabs * KS * TM * TK;
+    const int n = slabs * KS;
+    float* tmp = partial + (int64_t)n * TM * TK;                                      // level-1 sums
+    float* bias_partial = tmp + (int64_t)((n + kReduceGroup - 1) / kReduceGroup) * TM * TK;
     hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), 0, stream, dA, lda, 0, X, ldx, 0, P, slab,
                        partial, gb ? bias_partial : nullptr);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((TM * TK + 255) / 256), dim3(256), 0, stream, partial, slabs * KS, TM,
-                       TK, gw, w_ld, w_col0, rows_valid, cols_valid);
-    if (gb)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3((TM + 255) / 256), dim3(256), 0, stream, bias_partial, slabs * KS,
-                           1, TM, gb, TM, 0, 1, rows_valid);
+    reduce_tiles(partial, n, TM, TK, tmp, gw, w_ld, w_col0, rows_valid, cols_valid, stream);
+    if (gb) reduce_tiles(bias_partial, n, 1, TM, tmp, gb, TM, 0, 1, rows_valid, stream);
     return check_launch("dw_gemm");
 }
 
@@ -382,32 +647,79 @@ static int run_head(const float* dpre, int c0, int nc, const float* H, int ldh, 
                     float* gw, float* gb, hipStream_t stream) {
     const int slab = slab_points(P);
     const int slabs = (int)((P + slab - 1) / slab);
-    float* bias_partial = partial + (int64_t)slabs * 4 * 256;
-    hipLaunchKernelGGL(head_grad_kernel, dim3(slabs), dim3(256), 0, stream, dpre, c0, nc, H, ldh, F, P, slab, partial,
+    float* tmp = partial + (int64_t)slabs * 4 * 256;
+    float* bias_partial = tmp + (int64_t)((slabs + kReduceGroup - 1) / kReduceGroup) * 4 * 256;
+    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, dpre, 4, c0, nc, H, ldh, F, P, slab, partial,
                        bias_partial);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(4), dim3(256), 0, stream, partial, slabs, 4, 256, gw, F, 0, nc, F);
+    reduce_tiles(partial, slabs, 4, 256, tmp, gw, F, 0, nc, F, stream);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, bias_partial, slabs, 1, 4, gb, 4, 0, 1, nc);
     return check_launch("head_grad");
+}
+
+// bias gradient of a layer with no GEMM job (K = 3 inputs): column sums of dA over the points
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dA, int lda, int F, int64_t P,
+                                                     int slab_pts, float* __restrict__ partial) {
+    const int f = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
+    const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
+    float s = 0.f;
+    if (f < F) for (int64_t p = p0; p < p1; ++p) s += dA[p * lda + f];
+    partial[(int64_t)blockIdx.x * 256 + f] = s;
+}
+
+static int run_colsum(const float* dA, int lda, int F, int64_t P, float* partial, float* gb, hipStream_t stream) {
+    const int slab = slab_points(P);
+    const int slabs = (int)((P + slab - 1) / slab);
+    float* tmp = partial + (int64_t)slabs * 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(slabs), dim3(256), 0, stream, dA, lda, F, P, slab, partial);
+    reduce_tiles(partial, slabs, 1, 256, tmp, gb, 256, 0, 1, F, stream);
+    return check_launch("colsum");
+}
+
+// dW[:, col0:col0+3] of a layer whose inputs include the raw xyz (c0 = 0) or view direction (c0 = 3)
+static int run_k3(const float* xin, int c0, const float* dA, int lda, int F, int64_t P, float* partial, float* gw,
+                  int w_ld, int w_col0, hipStream_t stream) {
+    const int slab = slab_points(P);
+    const int slabs = (int)((P + slab - 1) / slab);
+    float* tmp = partial + (int64_t)slabs * 4 * 256;
+    float* bias_partial = tmp + (int64_t)((slabs + kReduceGroup - 1) / kReduceGroup) * 4 * 256;
+    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, xin, 8, c0, 3, dA, lda, F, P, slab, partial,
+                       bias_partial);
+    const float* src = partial;
+    int n = slabs;
+    if (n > kReduceGroup) {
+        const int groups = (n + kReduceGroup - 1) / kReduceGroup;
+        hipLaunchKernelGGL(reduce_level1_kernel, dim3(1, groups), dim3(256), 0, stream, partial, n, 1024, tmp);
+        src = tmp; n = groups;
+    }
+    hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(256), 0, stream, src, n, 3, F, gw, w_ld, w_col0);
+    return check_launch("k3_grad");
 }
 
 // Backward of a NeRF / TinyNeRF field over P points.  grad_params[2i], [2i+1]: device pointers to the weight /
 // bias gradient tensors (torch layout), overwritten.
 int launch_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads, const float* raw,
-                          const float* g_raw, int64_t P, float* partial, float* const* gp, hipStream_t stream) {
+                          const float* g_raw, int64_t n_groups, int64_t points_per_group, const float* film,
+                          float* film_partial, float* grad_film, float* partial, float* const* gp,
+                          hipStream_t stream) {
+    const int64_t P = n_groups * points_per_group;
     if (P <= 0) return 0;
-    if (kind != 0 && kind != 4) { set_error("backward is implemented for NeRF / TinyNeRF kinds (got %d)", kind); return -1; }
+    if (kind < 0 || kind > 4) { set_error("unknown field kind %d", kind); return -1; }
     static bool attr_done = false;
     const size_t lds = kLdsFloats * sizeof(float);
     if (!attr_done) {
-        const void* fns[] = {(const void*)nerf_bwd_kernel<false>, (const void*)nerf_bwd_kernel<true>};
+        const void* fns[] = {(const void*)nerf_bwd_kernel<false>, (const void*)nerf_bwd_kernel<true>,
+                             (const void*)siren_bwd_kernel, (const void*)film_bwd_kernel<true>,
+                             (const void*)film_bwd_kernel<false>};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 set_error("hipFuncSetAttribute failed"); return -2;
             }
         attr_done = true;
     }
-    BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P};
-    const unsigned blocks = (unsigned)((P + 127) / 128);
+    const int64_t tpg = (points_per_group + 127) / 128;
+    BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P, film, film_partial, points_per_group, tpg, n_groups * tpg};
+    const unsigned blocks = (unsigned)((kind == 2 || kind == 3) ? n_groups * tpg : (P + 127) / 128);
     int rc;
     if (kind == 0) {
         hipLaunchKernelGGL(nerf_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
@@ -429,6 +741,51 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
         // heads: sigma (row 3 of dpre) x H8, rgb (rows 0..2) x H_d
         if ((rc = run_head(G(10), 3, 1, A(8), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
         if ((rc = run_head(G(10), 0, 3, A(11), 128, 128, P, partial, gp[22], gp[23], stream))) return rc;
+    } else if (kind == 1) {
+        hipLaunchKernelGGL(siren_bwd_kernel, dim3(blocks), dim3(256), lds, stream, a);
+        if ((rc = check_launch("siren_bwd_kernel"))) return rc;
+        constexpr RegionLayout AL = siren_acts(), GL = siren_grads();
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
+        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
+        // layers_pos.0 (K = 3): dW = dA0^T xyz, bias = column sums of dA0 (taken by a K=... GEMM-free reduction)
+        if ((rc = run_k3(A(0), 0, G(0), 256, 256, P, partial, gp[0], 3, 0, stream))) return rc;
+        for (int l = 1; l <= 7; ++l) {           // input of layer l is X_l = acts region 2l-1
+            const int ldw = l == 5 ? 259 : 256, col0 = l == 5 ? 3 : 0;
+            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(2 * l - 1), 256, P, partial, gp[2 * l], ldw, col0, 256, 256, gp[2 * l + 1], stream))) return rc;
+        }
+        if ((rc = run_k3(A(0), 0, G(5), 256, 256, P, partial, gp[10], 259, 0, stream))) return rc;
+        // bias of layers_pos.0: ride on a (256 x 32) GEMM against the first saved block is wasteful; use the thin
+        // kernel with S = ones instead: column sums of dA0 = sum_p 1 * dA0[p][f]  -> computed by run_bias below
+        if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(15), 256, P, partial, gp[16], 256, 0, 256, 256, gp[17], stream))) return rc;   // layers_dir.0 x X8
+        if ((rc = run_gemm<4, 1, 2>(G(9), 128, A(17), 256, P, partial, gp[18], 259, 0, 128, 256, gp[19], stream))) return rc;   // layers_dir.1 x G
+        if ((rc = run_k3(A(0), 3, G(9), 128, 128, P, partial, gp[18], 259, 256, stream))) return rc;                             // ... x dir
+        if ((rc = run_head(G(10), 3, 1, A(15), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;                       // sigma x X8
+        if ((rc = run_head(G(10), 0, 3, A(18), 128, 128, P, partial, gp[22], gp[23], stream))) return rc;                       // rgb x X_d
+        if ((rc = run_colsum(G(0), 256, 256, P, partial, gp[1], stream))) return rc;                                            // bias layers_pos.0
+    } else if (kind == 2 || kind == 3) {
+        const bool use_dir = kind == 2;
+        if (!film || !film_partial || !grad_film) { set_error("FiLM backward needs film, film_partial, grad_film"); return -1; }
+        if (use_dir) hipLaunchKernelGGL(film_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL(film_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
+        if ((rc = check_launch("film_bwd_kernel"))) return rc;
+        hipLaunchKernelGGL(film_reduce_kernel, dim3((unsigned)n_groups, kFilmLayers), dim3(256), 0, stream, film_partial,
+                           n_groups * tpg, tpg, grad_film);
+        constexpr RegionLayout AL = film_acts();
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
+        const auto G = [&](int l) { return grads + (int64_t)(256 * l) * P; };
+        // input_layer (K = 3)
+        if ((rc = run_k3(A(0), 0, G(0), 256, 256, P, partial, gp[0], 3, 0, stream))) return rc;
+        if ((rc = run_colsum(G(0), 256, 256, P, partial, gp[1], stream))) return rc;
+        for (int l = 1; l <= 7; ++l)             // hidden_layers[l-1]: input X_{l-1} = acts region 2 + 3(l-1)
+            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(2 + 3 * (l - 1)), 256, P, partial, gp[2 * l], 256, 0, 256, 256, gp[2 * l + 1], stream))) return rc;
+        // hidden_layer_rgb (param 9): [X_7 | dir]
+        const int ld9 = use_dir ? 259 : 256;
+        if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(23), 256, P, partial, gp[18], ld9, 0, 256, 256, gp[19], stream))) return rc;
+        if (use_dir && (rc = run_k3(A(0), 3, G(8), 256, 256, P, partial, gp[18], 259, 256, stream))) return rc;
+        // heads: sigma (param 8) on X_7, rgb (param 10) on X_8
+        const float* dpre = grads + (int64_t)(9 * 256) * P;
+        if ((rc = run_head(dpre, 3, 1, A(23), 256, 256, P, partial, gp[16], gp[17], stream))) return rc;
+        if ((rc = run_head(dpre, 0, 3, A(26), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
     } else {
         hipLaunchKernelGGL(nerf_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
         if ((rc = check_launch("nerf_bwd_kernel"))) return rc;

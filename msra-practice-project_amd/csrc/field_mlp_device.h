@@ -138,6 +138,45 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
     }
 }
 
+// Training flavour of the sin activations: besides X = sin(30 u) it stores, as [point][feature] rows, X and
+// the derivative factor C = 30 cos(30 u) (and for FiLM the linear output A, needed for d gamma).
+template <int MB, int ACT>
+__device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
+                                               float* __restrict__ a_rows, float* __restrict__ x_rows,
+                                               float* __restrict__ c_rows, int64_t ld, int64_t p, bool valid) {
+    static_assert(ACT == ACT_SIN30 || ACT == ACT_FILM, "sin activations only");
+    lds4_t pf = nullptr;
+    if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
+    f32x4* arow = reinterpret_cast<f32x4*>(a_rows + p * ld + 4 * h);
+    f32x4* xrow = reinterpret_cast<f32x4*>(x_rows + p * ld + 4 * h);
+    f32x4* crow = reinterpret_cast<f32x4*>(c_rows + p * ld + 4 * h);
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 g, b, xo, co, ao;
+            if constexpr (ACT == ACT_FILM) {
+                g = pf[m * 8 + rg * 2];
+                b = pf[64 + m * 8 + rg * 2];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = acc[m][4 * rg + q];
+                float u = v;
+                if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), b[q]);
+                const SinCos sc = fast_sincos(__fmul_rn(30.f, u));
+                X[m][4 * rg + q] = sc.s;
+                xo[q] = sc.s; co[q] = 30.f * sc.c; ao[q] = v;
+            }
+            if (valid) {
+                xrow[m * 8 + rg * 2] = xo;
+                crow[m * 8 + rg * 2] = co;
+                if constexpr (ACT == ACT_FILM) arow[m * 8 + rg * 2] = ao;
+            }
+        }
+    }
+}
+
 // One MFMA layer: KB K blocks; bsel(kb) yields the B-operand register block of K block kb.
 // On entry the layer's first stage (aux + K block 0) has been issued into aux slot
 // `aux_slot` and chunk buffer PAR0.  NEXT_* describe the stage to issue while the last K block
