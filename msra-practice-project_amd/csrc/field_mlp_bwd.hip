@@ -394,15 +394,36 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     layer_bwd(0);                                                                               // input_layer
 }
 
-// d film[g][l][0:256] = sum over the group's tiles and waves of the gamma partials, [256:512] the beta ones
-__global__ void film_reduce_kernel(const float* __restrict__ part, int64_t n_tiles, int64_t tiles_per_group,
-                                   float* __restrict__ dfilm) {
+// d film[g][l][0:256] = sum over the group's tiles and waves of the gamma partials, [256:512] the beta ones.
+// Two levels, fixed order: level 1 sums kFilmRows-row chunks (grid = (chunks, groups, layers)) into a scratch
+// placed after the partials, level 2 sums the chunks.
+constexpr int kFilmRows = 64;
+
+__global__ __launch_bounds__(256) void film_reduce1_kernel(const float* __restrict__ part, int64_t n_tiles,
+                                                           int64_t tiles_per_group, float* __restrict__ tmp) {
+    const int l = blockIdx.z;
+    const int64_t g = blockIdx.y;
+    const int64_t rows = tiles_per_group * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * kFilmRows;
+    const int64_t r1 = r0 + kFilmRows < rows ? r0 + kFilmRows : rows;
+    const float* src = part + (((int64_t)l * n_tiles + g * tiles_per_group) * 4) * 512;
+    const int64_t chunks = gridDim.x;
+    float* dst = tmp + (((int64_t)l * gridDim.y + g) * chunks + blockIdx.x) * 512;
+    for (int f = threadIdx.x; f < 512; f += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += src[r * 512 + f];
+        dst[f] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void film_reduce2_kernel(const float* __restrict__ tmp, int64_t chunks,
+                                                           float* __restrict__ dfilm) {
     const int l = blockIdx.y;
     const int64_t g = blockIdx.x;
-    for (int f = threadIdx.x; f < 512; f += blockDim.x) {
+    const float* src = tmp + (((int64_t)l * gridDim.x + g) * chunks) * 512;
+    for (int f = threadIdx.x; f < 512; f += 256) {
         float s = 0.f;
-        const float* src = part + (((int64_t)l * n_tiles + g * tiles_per_group) * 4) * 512 + f;
-        for (int64_t t = 0; t < tiles_per_group * 4; ++t) s += src[t * 512];
+        for (int64_t k = 0; k < chunks; ++k) s += src[k * 512 + f];
         dfilm[(g * kFilmLayers + l) * kFilmRow + f] = s;
     }
 }
@@ -588,7 +609,9 @@ int64_t train_grads_floats(int kind) {
 }
 // per-tile FiLM partial sums: [9 layers][tiles][4 waves][512]
 int64_t film_partial_floats(int64_t n_groups, int64_t points_per_group) {
-    return (int64_t)kFilmLayers * n_groups * ((points_per_group + 127) / 128) * 4 * 512;
+    const int64_t tpg = (points_per_group + 127) / 128;
+    const int64_t chunks = (tpg * 4 + kFilmRows - 1) / kFilmRows;
+    return (int64_t)kFilmLayers * n_groups * (tpg * 4 + chunks) * 512;
 }
 
 static int slab_points(int64_t P) {
@@ -768,8 +791,14 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
         if (use_dir) hipLaunchKernelGGL(film_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
         else hipLaunchKernelGGL(film_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
         if ((rc = check_launch("film_bwd_kernel"))) return rc;
-        hipLaunchKernelGGL(film_reduce_kernel, dim3((unsigned)n_groups, kFilmLayers), dim3(256), 0, stream, film_partial,
-                           n_groups * tpg, tpg, grad_film);
+        {
+            const int64_t chunks = (tpg * 4 + kFilmRows - 1) / kFilmRows;
+            float* tmp = film_partial + (int64_t)kFilmLayers * n_groups * tpg * 4 * 512;
+            hipLaunchKernelGGL(film_reduce1_kernel, dim3((unsigned)chunks, (unsigned)n_groups, kFilmLayers), dim3(256), 0,
+                               stream, film_partial, n_groups * tpg, tpg, tmp);
+            hipLaunchKernelGGL(film_reduce2_kernel, dim3((unsigned)n_groups, kFilmLayers), dim3(256), 0, stream, tmp,
+                               chunks, grad_film);
+        }
         constexpr RegionLayout AL = film_acts();
         const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
         const auto G = [&](int l) { return grads + (int64_t)(256 * l) * P; };

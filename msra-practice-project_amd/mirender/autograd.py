@@ -16,8 +16,14 @@ import torch
 
 from . import _lib, fields, ops
 
-MAX_POINTS_PER_CHUNK = 1 << 19     # ~10 GB of saved activations + per-layer gradients for a NeRF field
-SAVE_IN_FORWARD_BYTES = 24 << 30   # keep layer inputs from the forward when they fit (no recompute in backward)
+CHUNK_BYTES = 48 << 30             # saved activations + per-layer gradients per backward chunk (288 GB of HBM)
+SAVE_IN_FORWARD_BYTES = 48 << 30   # keep layer inputs from the forward when they fit (no recompute in backward)
+
+
+def _max_points_per_chunk(pf) -> int:
+    lib = _lib.load()
+    per_point = 4 * (lib.mi_field_train_acts_floats(pf.kind) + lib.mi_field_train_grads_floats(pf.kind))
+    return max(4096, CHUNK_BYTES // per_point)
 
 
 def _groups(pf, film, n_rays):
@@ -63,9 +69,9 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, acts=None
     if acts is not None:
         groups_per_chunk = groups
     else:
-        groups_per_chunk = max(1, MAX_POINTS_PER_CHUNK // (rpg * s)) if f_all is not None else 1
+        groups_per_chunk = max(1, _max_points_per_chunk(pf) // (rpg * s)) if f_all is not None else 1
     rays_per_chunk = groups_per_chunk * rpg if f_all is not None else (n if acts is not None else
-                                                                        max(1, MAX_POINTS_PER_CHUNK // s))
+                                                                        max(1, _max_points_per_chunk(pf) // s))
     total = None
     g_film = None if f_all is None else torch.empty_like(f_all)
     packed_bwd = pf.refresh_bwd()
