@@ -47,7 +47,7 @@ def build(force=False, verbose=True):
             cmd = [hipcc, *COMMON, *extra, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            subprocess.check_call(cmd, timeout=1500)
     if force or _stale(OUT, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
         if verbose:

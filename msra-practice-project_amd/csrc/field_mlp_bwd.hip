@@ -458,22 +458,27 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = 4;    // point pairs in flight per wave
-    for (int64_t t0 = p0 + 2 * ks; t0 < p1; t0 += 2 * KS * U) {
-        f32x4 av[U];
-        bvec bv[U];
+    constexpr int U = 4;    // point pairs per step; the next step's rows are loaded before this step's MFMAs
+    const int64_t step = 2 * KS * U;
+    f32x4 av[U], an[U];
+    bvec bv[U], bn[U];
+    const auto fetch = [&](int64_t t0, f32x4 (&a)[U], bvec (&b)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t p = t0 + 2 * KS * u + h;
             if (p < p1) {
-                av[u] = *reinterpret_cast<const f32x4*>(arow + p * lda);
-                bv[u] = *reinterpret_cast<const bvec*>(brow + p * ldx);
+                a[u] = *reinterpret_cast<const f32x4*>(arow + p * lda);
+                b[u] = *reinterpret_cast<const bvec*>(brow + p * ldx);
             } else {
-                av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int d = 0; d < CB; ++d) bv[u][d] = 0.f;
+                for (int d = 0; d < CB; ++d) b[u][d] = 0.f;
             }
         }
+    };
+    fetch(p0 + 2 * ks, av, bv);
+    for (int64_t t0 = p0 + 2 * ks; t0 < p1; t0 += step) {
+        fetch(t0 + step, an, bn);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             bsum += av[u];
@@ -483,6 +488,8 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
                 for (int d = 0; d < CB; ++d)
                     acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
     }
     // write the partial tile: D[row i'][col j] on lane (j, h), reg r: i' = (r&3) + 8*(r>>2) + 4*h
     float* out = partial + ((int64_t)blockIdx.x * KS + ks) * TM * TK;
