@@ -89,8 +89,10 @@ def _generic_field(network, rays, z, chunk=1024 * 64):
 
 
 def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fine_sample_num, *,
-                t_rand=None, seed=None):
-    """nerf/render.py:106-147.  rays [N,2,3] -> (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f)."""
+                t_rand=None, seed=None, film=None):
+    """nerf/render.py:106-147.  rays [N,2,3] -> (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f).
+    `film` [b,9,512] (FiLM fields only) renders b images in one call: rays are b equal consecutive groups and
+    group g uses film[g]; by default the model's own film_params (one image) are used like the reference."""
     dev = _device_of(coarse_model, fine_model, rays=rays)
     rays = torch.as_tensor(rays).to(device=dev, dtype=torch.float32).reshape(-1, 2, 3).contiguous()
     nc, nf = int(coarse_sample_num), int(fine_sample_num)
@@ -99,10 +101,12 @@ def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fi
     pf_c, pf_f = fields.as_packed_field(coarse_model), fields.as_packed_field(fine_model)
     if pf_c is not None and pf_f is not None:
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in pf_c.params + pf_f.params)
-        film = None
         if fields.is_film(pf_c.kind) or fields.is_film(pf_f.kind):
-            film = fields.film_table(coarse_model if fields.is_film(pf_c.kind) else fine_model)
+            if film is None:
+                film = fields.film_table(coarse_model if fields.is_film(pf_c.kind) else fine_model)
             needs_grad = needs_grad or (torch.is_grad_enabled() and film.requires_grad)
+        else:
+            film = None
         if needs_grad:
             from . import autograd
             return autograd.render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0)

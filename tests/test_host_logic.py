@@ -84,3 +84,23 @@ def test_film_table_from_reference_style_params():
     m.set_film_params(mapping)                       # list of 9 (gamma, beta) chunks, pi_GAN/modules.py:96-99
     assert len(m.film_params) == 9 and m.film_params[0][0].shape == (256,)
     assert torch.equal(fields.film_table(m)[0], mapping)
+
+
+def test_pigan_generator_state_dict_layout():
+    """Generator's parameters carry the reference's names (pi_GAN/modules.py:165-175) so its checkpoints
+    ('generator' entry of pi_GAN/train.py:162-172) load."""
+    from mirender import pigan
+    g = pigan.Generator(64, 16)
+    keys = set(g.state_dict().keys())
+    assert {"film_siren_nerf.input_layer.weight", "film_siren_nerf.hidden_layers.6.bias",
+            "film_siren_nerf.output_layer_sigma.0.weight", "film_siren_nerf.hidden_layer_rgb.weight",
+            "film_siren_nerf.output_layer_rgb.0.bias", "mapping_network.input_layer.0.weight",
+            "mapping_network.hidden_layers.0.weight", "mapping_network.hidden_layers.2.bias",
+            "mapping_network.output_layers.8.weight"} <= keys
+    assert sum(p.numel() for p in g.parameters()) == 529156 + (64 * 256 + 256) + 2 * (256 * 256 + 256) + 9 * (256 * 512 + 512)
+    out = g.get_mapping(torch.zeros(2, 64))
+    assert tuple(out.shape) == (2, 9, 512)
+    r = g.renderer
+    assert abs(float(r.focal) - 16 / 2 / np.tan(6 * np.pi / 180)) < 1e-9
+    g.set_resolution(32)
+    assert r.width == 32 and abs(float(r.focal) - 32 / 2 / np.tan(6 * np.pi / 180)) < 1e-9
