@@ -133,12 +133,91 @@ def cpu_baseline(sample_rays=8192):
                       f"NeRF coarse+fine, torch CPU no_grad, {dt:.1f} s"}
 
 
+def train_workload(args, world, rank, dev):
+    """Secondary workloads (not the headline line): one training step per `step`, data-parallel over ranks
+    (each rank its own batch = weak scaling) with one flat RCCL all-reduce of the renderer gradients.
+      c4          pi_GAN generator step, 128x128, batch 32 per GPU, Nc=12 Nf=24 (BASELINE config C4)
+      nerf_train  nerf/train_nerf.py step: 1024 rays per GPU, 64+128 samples, coarse+fine NeRF, Adam"""
+    from mirender import dist as mdist, fields, pigan, render_core
+    torch.manual_seed(rank)
+    if args.workload == "c4":
+        res, b, nc, nf = 128, 32, 12, 24
+        gen = pigan.Generator(256, res, near=0.5, far=1.5, fov=12, coarse_samples=nc, fine_samples=nf).to(dev)
+        params = list(gen.parameters())
+        opt = torch.optim.Adam(params, lr=5e-5, betas=(0.0, 0.9))
+        z = torch.randn(b, 256, device=dev)
+        rays_per_step = b * res * res
+        flops = rays_per_step * (nc + 3 * (nc + nf)) * fields.FLOPS_PER_POINT[fields.FILM_SIREN_NERF]
+
+        def step(i):
+            img = gen(z, seed=100 + i)
+            loss = torch.nn.functional.softplus(-img.mean(dim=(1, 2, 3))).mean()   # stand-in for -D(G(z))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            mdist.allreduce_grads(params)
+            opt.step()
+        name = "pi_GAN generator training step 128x128, batch 32/GPU, 12+24 samples (BASELINE config C4), fwd+bwd+Adam"
+    else:
+        n, nc, nf = 1024, 64, 128
+        coarse, fine = make_models(dev)
+        params = list(coarse.parameters()) + list(fine.parameters())
+        opt = torch.optim.Adam(params, lr=5e-4)
+        rays = torch.randn(n, 2, 3, device=dev)
+        rays[:, 0] = torch.tensor([0.0, 0.0, 4.0], device=dev)
+        rays[:, 1, 2] = -1.0
+        tgt = torch.rand(n, 4, device=dev)
+        rays_per_step = n
+        flops = rays_per_step * 3 * (nc + nc + nf) * fields.FLOPS_PER_POINT[fields.NERF]
+
+        def step(i):
+            rgb_c, _, acc_c, rgb_f, _, acc_f = render_core.render_rays(rays, NEAR, FAR, coarse, fine, nc, nf, seed=i)
+            loss = sum(torch.mean((r - tgt[:, :3]) ** 2) + 0.1 * torch.mean((a - tgt[:, 3]) ** 2)
+                       for r, a in ((rgb_f, acc_f), (rgb_c, acc_c)))            # train_nerf.py:158-167
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            mdist.allreduce_grads(params)
+            opt.step()
+        name = "nerf/train_nerf.py step: 1024 rays/GPU, 64+128 samples, coarse+fine NeRF 8x256, fwd+bwd+Adam"
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        achieved = flops * args.steps / elapsed / 1e12
+        print(json.dumps({
+            "metric": "rays/sec (training step)", "value": world * rays_per_step * args.steps / elapsed, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step,
+                       "parallelism": f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU"},
+            "roofline": {"bound": "mfma", "kernel": "whole training step (forward, backward chain, dW GEMMs)",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "note": "algorithmic FLOPs = 2 x MACs x (1 per no-grad pass + 3 per trained pass), SURVEY.md 8d"},
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "nerf_train"],
+                    help="c3 (default, the headline line) | c4 | nerf_train (secondary training workloads)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +228,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.workload != "c3":
+        train_workload(args, world, rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     from mirender import _lib, dist as mdist, fields
     lib = _lib.load()
