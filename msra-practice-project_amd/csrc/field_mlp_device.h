@@ -134,8 +134,8 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
                 const float v = acc[m][4 * rg + q];
                 float o;
                 if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
-                else if constexpr (ACT == ACT_SIN30) o = fast_sin(__fmul_rn(30.f, v));
-                else if constexpr (ACT == ACT_FILM) o = fast_sin(__fmul_rn(30.f, __fadd_rn(__fmul_rn(g[q], v), b[q])));
+                else if constexpr (ACT == ACT_SIN30) o = hw_sin30(v);
+                else if constexpr (ACT == ACT_FILM) o = hw_sin30(__fadd_rn(__fmul_rn(g[q], v), b[q]));
                 else o = v;
                 X[m][4 * rg + q] = o;
             }
@@ -169,7 +169,7 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
                 const float v = acc[m][4 * rg + q];
                 float u = v;
                 if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), b[q]);
-                const SinCos sc = fast_sincos(__fmul_rn(30.f, u));
+                const SinCos sc = hw_sincos30(u);
                 X[m][4 * rg + q] = sc.s;
                 xo[q] = sc.s; co[q] = 30.f * sc.c; ao[q] = v;
             }

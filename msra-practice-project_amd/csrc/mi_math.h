@@ -38,4 +38,22 @@ __device__ __forceinline__ SinCos fast_sincos(float x) {
 
 __device__ __forceinline__ float fast_sin(float x) { return fast_sincos(x).s; }
 
+// sin / cos of 30*u on the hardware transcendental unit (v_sin_f32 / v_cos_f32 take revolutions):
+// t = u * 30/(2 pi) as a two-float product so the fractional part keeps 24 good bits whatever |u|, then
+// v_fract + v_sin.  Measured on MI355X against fp64 over |u| < 40: max abs error 3.8e-7 (the polynomial above:
+// 7e-8) at ~6 instructions instead of ~22.  Used for the SIREN / FiLM activations sin(30 u)
+// (nerf/nerf.py:112, pi_GAN/modules.py:25); the positional encoding keeps the polynomial.
+__device__ __forceinline__ float hw_frac30(float u) {
+    const float c_hi = 4.77464829275686f;                                       // 30 / (2 pi)
+    const float c_lo = (float)(4.774648292756860073 - (double)4.77464829275686f);
+    const float hi = u * c_hi;
+    const float lo = fmaf(u, c_hi, -hi) + u * c_lo;
+    return __builtin_amdgcn_fractf(hi) + lo;
+}
+__device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(hw_frac30(u)); }
+__device__ __forceinline__ SinCos hw_sincos30(float u) {
+    const float f = hw_frac30(u);
+    return {__builtin_amdgcn_sinf(f), __builtin_amdgcn_cosf(f)};
+}
+
 }  // namespace mi
