@@ -268,7 +268,7 @@ __device__ __forceinline__ void posenc_blocks(float* scr, int lane, int h, float
             const int i = f / 6, cc = f - 6 * i;
             const int comp = cc >= 3 ? cc - 3 : cc;
             const float xv = comp == 0 ? x : (comp == 1 ? y : z);
-            const SinCos sc = fast_sincos(ldexpf(xv, i));
+            const SinCos sc = hw_sincos(ldexpf(xv, i));
             v = cc >= 3 ? sc.c : sc.s;
         }
         scr[slot * 64 + lane] = v;
