@@ -75,8 +75,10 @@ __device__ __forceinline__ void issue_stage(Ctx& c, int aux_slot, int chunk_buf,
 // hipcc schedules this as {2 reads, wait, 8 MFMAs} per pair of fragments.  A hand-pipelined variant (reads one
 // pair ahead, pinned with sched_group_barrier) measured exactly the same 86.3 % of peak - the LDS latency is
 // already covered by the 64-cycle MFMAs still in the pipe - so the plain form is kept.
-template <int MB>
-__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8]) {
+// `mid()` runs after the first quarter of the block's MFMAs have been issued: the next stage's DMA is
+// issued there, in the shadow of the matrix pipe, instead of between the barrier and the first MFMA.
+template <int MB, class Mid>
+__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8], Mid mid) {
     const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + lane;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
@@ -88,6 +90,7 @@ __device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f3
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * rg + 2], acc[m], 0, 0, 0);
             acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * rg + 3], acc[m], 0, 0, 0);
         }
+        if (rg == 0) mid();
     }
 }
 
@@ -193,10 +196,11 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
         constexpr int kb = decltype(kbc)::value;
         constexpr int cur = (PAR0 + kb) & 1;
         __syncthreads();
-        if constexpr (kb + 1 < KB) issue_stage<0, MB * 4, false>(c, 0, cur ^ 1, 0);
-        else issue_stage<NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot ^ 1, cur ^ 1, next_film_layer);
         if constexpr (kb == 0) init(acc);
-        mma_chunk<MB>(c.smem + kLdsChunk0 + cur * kLdsChunk, c.lane, bsel(kbc), acc);
+        mma_chunk<MB>(c.smem + kLdsChunk0 + cur * kLdsChunk, c.lane, bsel(kbc), acc, [&]() {
+            if constexpr (kb + 1 < KB) issue_stage<0, MB * 4, false>(c, 0, cur ^ 1, 0);
+            else issue_stage<NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot ^ 1, cur ^ 1, next_film_layer);
+        });
     };
     static_for<KB>(stage);
 }
