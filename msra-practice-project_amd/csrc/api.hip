@@ -12,6 +12,9 @@ namespace mi {
 
 static thread_local char g_err[512] = "";
 static thread_local hipEvent_t g_mlp_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+#ifdef MI_PROFILE_STAMPS
+static unsigned long long* g_stamps = nullptr;
+#endif
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -54,6 +57,11 @@ static int eval_common(int kind, const float* packed, const float* film, const f
     args.packed = packed; args.film = is_film(kind) ? film : nullptr; args.a = a; args.z = z; args.out = out;
     args.points_per_group = ppg; args.rays_per_group = rpg; args.tiles_per_group = (ppg + 127) / 128;
     args.n_samples = S; args.mode = mode; args.save = save; args.save_points = n_groups * ppg;
+#ifdef MI_PROFILE_STAMPS
+    args.stamps = g_stamps;
+#else
+    args.stamps = nullptr;
+#endif
     return launch_mlp(kind, args, n_groups, s);
 }
 
@@ -229,6 +237,10 @@ int mi_field_backward(int kind, const float* packed_bwd, const float* film, cons
     return launch_field_backward(kind, packed_bwd, acts, grads_ws, raw, g_raw, n_groups, points_per_group, film,
                                  film_partial_ws, grad_film, partial_ws, grad_params, (hipStream_t)stream);
 }
+
+#ifdef MI_PROFILE_STAMPS
+void mi_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
+#endif
 
 void* mi_event_create(void) {
     hipEvent_t e = nullptr;

@@ -33,6 +33,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_profile(verbose=True):
+    """Diagnostic build with in-kernel cycle stamps (-DMI_PROFILE_STAMPS): gpurun_tools/libmirender_prof.so.
+    Never loaded by the product or the tests; used by tools/stamp_profile.py only."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(os.path.dirname(PKG), "gpurun_tools")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libmirender_prof.so")
+    srcs = [os.path.join(HERE, s) for s in SOURCES]
+    cmd = [hipcc, *COMMON, "-DMI_PROFILE_STAMPS", "-shared", *srcs, "-o", out]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, timeout=2400)
+    return out
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
@@ -57,4 +72,7 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--profile" in sys.argv:
+        print(build_profile())
+    else:
+        print(build(force="--force" in sys.argv))

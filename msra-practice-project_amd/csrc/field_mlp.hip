@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx(smem, a, group);
+    MI_STAMP(a, 0);
     issue_stage<1, 32, false>(c, 0, 0, 0);   // layer 0: bias + K block 0 (PE features 0..31)
 
     const PointIn pt = load_point(a.mode, a.a, a.z, group, a.points_per_group, a.rays_per_group, a.n_samples,
@@ -139,9 +140,12 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     };
 
     int slot = 0;
+    MI_STAMP(a, 1);
     // layers_pos[0]: 60 -> 256
     mma_layer<2, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc);
+    MI_STAMP(a, 2);
     activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
+    MI_STAMP(a, 3);
     save(64, 256, MB8{}, X);                                            // H1
     float sigma;
     if constexpr (!TINY) {
@@ -149,19 +153,26 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
             mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
+            MI_STAMP(a, 2 + 2 * l);
             activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
             save(64 + 256 * l, 256, MB8{}, X);                          // H2..H5
+            MI_STAMP(a, 3 + 2 * l);
         }
         // layers_pos[5]: [PE(60) | h(256)] -> 256
         mma_layer<10, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_skip, acc);
+        MI_STAMP(a, 12);
         activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
+        MI_STAMP(a, 13);
         save(region_offset(RL, 6), 256, MB8{}, X);                      // H6
         // layers_pos[6]
         mma_layer<8, 8, 0, false, 3, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
+        MI_STAMP(a, 14);
         activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
         save(region_offset(RL, 7), 256, MB8{}, X);                      // H7
+        MI_STAMP(a, 15);
         // layers_pos[7] (+ sigma head pieces)
         mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
+        MI_STAMP(a, 16);
         activate<8, ACT_RELU>(acc, X, nullptr, c.h);
         save(region_offset(RL, 8), 256, MB8{}, X);                      // H8
         {
@@ -169,9 +180,12 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
         }
         slot ^= 1;
+        MI_STAMP(a, 17);
         // layers_dir[0]: linear
         mma_layer<8, 8, 0, false, 5, 16, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
+        MI_STAMP(a, 18);
         activate<8, ACT_LINEAR>(acc, X, nullptr, c.h); slot ^= 1;
+        MI_STAMP(a, 19);
         save(region_offset(RL, 9), 256, MB8{}, X);                      // G
     } else {
         // layers_pos[1], [2], [3] (+ sigma head pieces), then the dir layer's 5 aux pieces
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     }
     // layers_dir[1] (TinyNeRF: layers_dir[0]): [h(256) | PE_dir(24)] -> 128, relu; then rgb head
     mma_layer<9, 4, 0, false, 0, 0, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_dir, acc);
+    MI_STAMP(a, 20);
     activate<4, ACT_RELU>(acc, X, nullptr, c.h);
     save(region_offset(RL, TINY ? 6 : 11), 128, MB4{}, X);              // H_d
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
@@ -199,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     const float g = sigmoidf(head_dot<4>(X, aux, 2, c.h) + aux[4 * kPiece + 1]);
     const float b = sigmoidf(head_dot<4>(X, aux, 3, c.h) + aux[4 * kPiece + 2]);
     store_out(a, pt, c.h, r, g, b, sigma);
+    MI_STAMP(a, 21);
 }
 
 // =========================================================================================

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a 128-point tile of the fused NeRF forward spends its cycles.
+
+Loads the STAMPED build (python msra-practice-project_amd/csrc/build.py --profile ->
+gpurun_tools/libmirender_prof.so), never the product library; wave 0 of every workgroup writes s_memtime at
+the phase boundaries of nerf_fwd_kernel.  Prints median cycles per phase.  Shares only: stamps perturb the run.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(ROOT, "gpurun_tools", "libmirender_prof.so"))
+vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+lib.mi_field_packed_floats.restype = i64
+lib.mi_field_pack.argtypes = [i32, ctypes.POINTER(vp), i32, vp, vp]
+lib.mi_field_eval_points.argtypes = [i32, vp, vp, vp, i64, i64, vp, vp]
+lib.mi_debug_set_stamps.argtypes = [vp]
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+shapes = [(256, 60)] + [(256, 256)] * 4 + [(256, 316), (256, 256), (256, 256), (256, 256), (128, 280), (1, 256), (3, 128)]
+params = []
+for o, i in shapes:
+    params += [torch.randn(o, i, device=dev) * (2.0 / (i + o)) ** 0.5, torch.zeros(o, device=dev)]
+packed = torch.empty(lib.mi_field_packed_floats(0), dtype=torch.float32, device=dev)
+arr = (vp * len(params))(*[p.data_ptr() for p in params])
+lib.mi_field_pack(0, arr, len(params), vp(packed.data_ptr()), None)
+M = 128 * 256 * 24                      # 24 tiles per CU
+x = torch.rand((M, 6), device=dev) * 2 - 1
+out = torch.empty((M, 4), device=dev)
+stamps = torch.zeros((M // 128, 32), dtype=torch.int64, device=dev)
+for rep in range(2):
+    lib.mi_debug_set_stamps(vp(stamps.data_ptr()))
+    lib.mi_field_eval_points(0, vp(packed.data_ptr()), None, vp(x.data_ptr()), 1, M, vp(out.data_ptr()), None)
+    torch.cuda.synchronize()
+s = stamps.cpu().numpy().astype(np.int64)
+names = {0: "entry", 1: "prologue (load point, PE)", 2: "L0 mfma (2 K-blocks)", 3: "L0 act"}
+for l in range(1, 5):
+    names[2 + 2 * l] = f"L{l} mfma (8)"
+    names[3 + 2 * l] = f"L{l} act"
+names.update({12: "L5 mfma (10)", 13: "L5 act", 14: "L6 mfma (8)", 15: "L6 act", 16: "L7 mfma (8)", 17: "L7 act + sigma head",
+              18: "dir0 mfma (8)", 19: "dir0 copy", 20: "dir1 mfma (9, MB=4)", 21: "dir1 act + rgb head + store"})
+ideal = {2: 2 * 8192, 12: 10 * 8192, 20: 9 * 4096}
+for k in (4, 6, 8, 10, 14, 16, 18):
+    ideal[k] = 8 * 8192
+body = s[512:]                                   # skip the first wave of workgroups (cold caches)
+total = np.median(body[:, 21] - body[:, 0])
+print(f"tile total (median) {total:.0f} cycles (memtime ticks); ideal MFMA 593920")
+acc_mfma = acc_ideal = 0
+for i in range(1, 22):
+    d = np.median(body[:, i] - body[:, i - 1])
+    extra = f"  ideal {ideal[i]}  overhead {d - ideal[i]:.0f}" if i in ideal else ""
+    if i in ideal:
+        acc_mfma += d; acc_ideal += ideal[i]
+    print(f"{i:2d} {names[i]:32s} {d:9.0f}  {100 * d / total:5.1f} %{extra}")
+print(f"mfma phases {acc_mfma:.0f} vs ideal {acc_ideal} -> {100 * acc_ideal / acc_mfma:.1f} % ; non-mfma phases {total - acc_mfma:.0f} ({100 * (total - acc_mfma) / total:.1f} %)")
+gaps = np.median(s[768:, 0] - s[512:-256, 21])    # start of a tile vs end of the tile 256 workgroups earlier (same CU, roughly)
+print(f"approx. workgroup turnaround on a CU: {gaps:.0f}")
