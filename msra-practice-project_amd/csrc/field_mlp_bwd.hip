@@ -123,9 +123,7 @@ __device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 template <bool TINY>
 __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    Ctx c;
-    c.smem = smem; c.wp = a.packed; c.film = nullptr;
-    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.h = c.lane >> 5;
+    Ctx c = make_ctx_raw(smem, a.packed, nullptr);
     constexpr RegionLayout AL = TINY ? tiny_acts() : nerf_acts();
     constexpr RegionLayout GL = TINY ? tiny_grads() : nerf_grads();
     constexpr int kHeadAux = TINY ? 4 : 3;                 // rgb rows (+ sigma row for TinyNeRF)
@@ -231,9 +229,7 @@ __device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)
 // =========================================================================================
 __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    Ctx c;
-    c.smem = smem; c.wp = a.packed; c.film = nullptr;
-    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.h = c.lane >> 5;
+    Ctx c = make_ctx_raw(smem, a.packed, nullptr);
     constexpr RegionLayout AL = siren_acts();
     constexpr RegionLayout GL = siren_grads();
     const int64_t P = a.points;
@@ -338,9 +334,7 @@ __device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 template <bool USE_DIR>
 __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    Ctx c;
-    c.smem = smem; c.wp = a.packed; c.film = nullptr;
-    c.lane = threadIdx.x & 63; c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); c.h = c.lane >> 5;
+    Ctx c = make_ctx_raw(smem, a.packed, nullptr);
     const int64_t P = a.points;
     issue_stage<4, 32, false>(c, 0, 0, 0);                 // rgb head rows x3, sigma row; K block 0 of hidden_layer_rgb^T
 

@@ -38,59 +38,96 @@ enum Act : int { ACT_LINEAR = 0, ACT_RELU = 1, ACT_SIN30 = 2, ACT_FILM = 3 };
 
 struct Ctx {
     float* smem;
-    const float* wp;        // next unread piece of the packed stream (wave-uniform)
-    const float* film;      // this group's FiLM table [9][512] or nullptr
+    __amdgpu_buffer_rsrc_t rsrc;    // buffer descriptor of the packed weight stream
+    __amdgpu_buffer_rsrc_t frsrc;   // ... of this group's FiLM table [9][512] (FiLM kinds)
+    int soff;                       // byte offset of the next unread piece of the stream (wave-uniform, SGPR)
+    int voff;                       // per-lane byte offset inside a round of 4 pieces: wave * 1024 + lane * 16
     int lane, wave, h;
+#ifdef MI_PROFILE_STAMPS
+    unsigned long long* stamps;   // diagnostic build: this block's stamp row
+    int stage_id;
+#endif
 };
 
-// DMA N consecutive 1 KiB pieces g -> lds, split over the 4 waves.  Full rounds of 4 pieces are issued
-// without a branch (a branch per piece splits the MFMA scheduling region the issue is hidden in).
-template <int N>
-__device__ __forceinline__ void dma_pieces(const float* g, float* lds, int wave, int lane) {
-#pragma unroll
-    for (int t0 = 0; t0 < N; t0 += 4) {
-        const int t = t0 + wave;
-        if (t0 + 4 <= N || t < N)
-            __builtin_amdgcn_global_load_lds((const MI_GLB void*)(g + t * kPiece + lane * 4),
-                                             (MI_LDS void*)(lds + t * kPiece), 16, 0, 0);
-    }
+#ifdef MI_PROFILE_STAMPS
+// stamps 22..27 bracket the barrier of one mid-kernel K-block stage (stage 40)
+#define MI_CSTAMP(c, i) do { if ((c).stage_id == 40 && threadIdx.x == 0 && (c).stamps) (c).stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MI_CSTAMP(c, i) do { } while (0)
+#endif
+
+// LDS-DMA of 1 KiB pieces (buffer_load_dwordx4 ... lds): per piece one SALU add for M0 and one VMEM issue -
+// SGPR soffset selects the piece, the VGPR offset is constant - so a piece can be slipped between two MFMAs.
+__device__ __forceinline__ void dma_piece(const Ctx& c, __amdgpu_buffer_rsrc_t r, int lds_float_off, int soff_bytes) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (MI_LDS void*)(c.smem + lds_float_off), 16, c.voff, soff_bytes, 0, 0);
 }
 
-// Issue the DMA of one stage: optional aux pieces (+ FiLM row) of a layer, then one K block.
+// N consecutive pieces starting at stream offset `soff` -> LDS float offset lds_off, split over the 4 waves.
+template <int N>
+__device__ __forceinline__ void dma_lump(const Ctx& c, __amdgpu_buffer_rsrc_t r, int soff, int lds_off) {
+#pragma unroll
+    for (int t0 = 0; t0 < N; t0 += 4)
+        if (t0 + 4 <= N || t0 + c.wave < N) dma_piece(c, r, lds_off + (t0 + c.wave) * kPiece, soff + t0 * 1024);
+}
+
+// Issue the DMA of one stage in one go: optional aux pieces (+ FiLM row) of a layer, then one K block.
 template <int N_AUX, int N_CHUNK_PIECES, bool FILM>
 __device__ __forceinline__ void issue_stage(Ctx& c, int aux_slot, int chunk_buf, int film_layer) {
     if constexpr (N_AUX > 0) {
-        dma_pieces<N_AUX>(c.wp, c.smem + kLdsAux0 + aux_slot * kLdsAux, c.wave, c.lane);
-        c.wp += N_AUX * kPiece;
-        if constexpr (FILM)
-            dma_pieces<2>(c.film + film_layer * kFilmRow, c.smem + kLdsFilm0 + aux_slot * kFilmRow, c.wave, c.lane);
+        dma_lump<N_AUX>(c, c.rsrc, c.soff, kLdsAux0 + aux_slot * kLdsAux);
+        c.soff += N_AUX * 1024;
+        if constexpr (FILM) dma_lump<2>(c, c.frsrc, film_layer * (kFilmRow * 4), kLdsFilm0 + aux_slot * kFilmRow);
     }
     if constexpr (N_CHUNK_PIECES > 0) {
-        dma_pieces<N_CHUNK_PIECES>(c.wp, c.smem + kLdsChunk0 + chunk_buf * kLdsChunk, c.wave, c.lane);
-        c.wp += N_CHUNK_PIECES * kPiece;
+        dma_lump<N_CHUNK_PIECES>(c, c.rsrc, c.soff, kLdsChunk0 + chunk_buf * kLdsChunk);
+        c.soff += N_CHUNK_PIECES * 1024;
     }
 }
 
-// 32-wide K block: acc[m] += W[32m.., kblock] * B, A fragments from LDS (4 MFMAs per b128 read).
-// hipcc schedules this as {2 reads, wait, 8 MFMAs} per pair of fragments.  A hand-pipelined variant (reads one
-// pair ahead, pinned with sched_group_barrier) measured exactly the same 86.3 % of peak - the LDS latency is
-// already covered by the 64-cycle MFMAs still in the pipe - so the plain form is kept.
-// `mid()` runs after the first quarter of the block's MFMAs have been issued: the next stage's DMA is
-// issued there, in the shadow of the matrix pipe, instead of between the barrier and the first MFMA.
-template <int MB, class Mid>
-__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8], Mid mid) {
+// The same stage issued piecewise from NSLOT call sites spread over a K block's first row of MFMAs:
+// slot 0 also issues the (rare) aux pieces; slot s issues this wave's chunk pieces s, s + NSLOT, ...
+template <int N_AUX, int N_CHUNK_PIECES, bool FILM, int NSLOT, int S>
+__device__ __forceinline__ void issue_stage_slot(Ctx& c, int aux_slot, int chunk_buf, int film_layer) {
+    if constexpr (S == 0 && N_AUX > 0) {
+        dma_lump<N_AUX>(c, c.rsrc, c.soff, kLdsAux0 + aux_slot * kLdsAux);
+        c.soff += N_AUX * 1024;
+        if constexpr (FILM) dma_lump<2>(c, c.frsrc, film_layer * (kFilmRow * 4), kLdsFilm0 + aux_slot * kFilmRow);
+    }
+    constexpr int NP = N_CHUNK_PIECES / 4;        // pieces per wave
+    static_assert(N_CHUNK_PIECES % 4 == 0, "K blocks are whole rounds of 4 pieces");
+#pragma unroll
+    for (int j = S; j < NP; j += NSLOT)
+        dma_piece(c, c.rsrc, kLdsChunk0 + chunk_buf * kLdsChunk + (4 * j + c.wave) * kPiece, c.soff + 4096 * j);
+    if constexpr (S == NSLOT - 1) c.soff += N_CHUNK_PIECES * 1024;
+}
+
+// One row of fragments (all MB output blocks of one rg) is read first, then its 4*MB MFMAs are issued q-major
+// so consecutive MFMAs hit MB different accumulators.  MFMA issue is in-order and blocking, so anything the
+// wave issues in one lump between two MFMAs idles the matrix pipe for its whole issue time (measured: 416
+// cycles for a lump of 8 DMA pieces).  The next stage's DMA is therefore issued piecewise: `slot(s)` is
+// called after every 4th MFMA of the first row (s = 0..MB-1), pinned there by sched_barrier.
+template <int MB, class Slot>
+__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8], Slot slot) {
     const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + lane;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
+        f32x4 a[MB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            const f32x4 a = a4[(rg * MB + m) * 64];
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[4 * rg + 0], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[4 * rg + 1], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[4 * rg + 2], acc[m], 0, 0, 0);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[4 * rg + 3], acc[m], 0, 0, 0);
-        }
-        if (rg == 0) mid();
+        for (int m = 0; m < MB; ++m) a[m] = a4[(rg * MB + m) * 64];
+        static_for<4>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            static_for<MB / 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+#pragma unroll
+                for (int m = 4 * g; m < 4 * g + 4; ++m)
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], acc[m], 0, 0, 0);
+                if (rg == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    slot(std::integral_constant<int, q * (MB / 4) + g>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
     }
 }
 
@@ -197,9 +234,10 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
         constexpr int cur = (PAR0 + kb) & 1;
         __syncthreads();
         if constexpr (kb == 0) init(acc);
-        mma_chunk<MB>(c.smem + kLdsChunk0 + cur * kLdsChunk, c.lane, bsel(kbc), acc, [&]() {
-            if constexpr (kb + 1 < KB) issue_stage<0, MB * 4, false>(c, 0, cur ^ 1, 0);
-            else issue_stage<NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot ^ 1, cur ^ 1, next_film_layer);
+        mma_chunk<MB>(c.smem + kLdsChunk0 + cur * kLdsChunk, c.lane, bsel(kbc), acc, [&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            if constexpr (kb + 1 < KB) issue_stage_slot<0, MB * 4, false, MB, S>(c, 0, cur ^ 1, 0);
+            else issue_stage_slot<NEXT_AUX, NEXT_CHUNK, FILM, MB, S>(c, aux_slot ^ 1, cur ^ 1, next_film_layer);
         });
     };
     static_for<KB>(stage);
@@ -314,15 +352,26 @@ __device__ __forceinline__ PointIn load_point(int mode, const float* __restrict_
     return o;
 }
 
-__device__ __forceinline__ Ctx make_ctx(float* smem, const MlpArgs& a, int64_t group) {
+__device__ __forceinline__ Ctx make_ctx_raw(float* smem, const float* packed, const float* film_group) {
     Ctx c;
     c.smem = smem;
-    c.wp = a.packed;
-    c.film = a.film ? a.film + group * (kFilmLayers * kFilmRow) : nullptr;
     c.lane = threadIdx.x & 63;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.h = c.lane >> 5;
+    // descriptors are built from wave-uniform values only; no bounds are relied on (num_records = 2 GiB)
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7fffffff, 0x00020000);
+    c.frsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(film_group ? film_group : packed), 0, 0x7fffffff, 0x00020000);
+    c.soff = 0;
+    c.voff = c.wave * 1024 + c.lane * 16;
+#ifdef MI_PROFILE_STAMPS
+    c.stamps = nullptr;
+    c.stage_id = 0;
+#endif
     return c;
+}
+
+__device__ __forceinline__ Ctx make_ctx(float* smem, const MlpArgs& a, int64_t group) {
+    return make_ctx_raw(smem, a.packed, a.film ? a.film + group * (kFilmLayers * kFilmRow) : nullptr);
 }
 
 __device__ __forceinline__ void store_out(const MlpArgs& a, const PointIn& pt, int h, float r, float g, float b,
