@@ -108,6 +108,11 @@ int mi_sample_fine(int64_t n, float near_, float far_, int n_coarse, int n_fine,
                    const float* u_lin, const float* z_coarse, const float* weights, float* z_samples,
                    float* z_fine, void* stream);
 
+/* sample_pdf as a free-standing function (nerf/render.py:27-56; star-imported by the reference's scripts):
+ * bins [n,n_bins], weights [n,n_bins-1] -> samples [n,n_samples]; u_lin [n_samples] optional table as above. */
+int mi_sample_pdf(int64_t n, int n_bins, int n_samples, const float* bins, const float* weights,
+                  const float* u_lin, float* samples, void* stream);
+
 /* ---- whole path ----------------------------------------------------------------- */
 
 /* render_rays (nerf/render.py:106-147) for known field kinds, all stages on `stream`.

@@ -138,6 +138,15 @@ int mi_sample_fine(int64_t n, float near_, float far_, int n_coarse, int n_fine,
                               (hipStream_t)stream);
 }
 
+int mi_sample_pdf(int64_t n, int n_bins, int n_samples, const float* bins, const float* weights, const float* u_lin,
+                  float* samples, void* stream) {
+    if (n < 0 || n_bins < 2 || n_samples < 0 || !bins || !weights || (n_samples > 0 && !samples)) {
+        set_error("mi_sample_pdf: bad arguments (need at least 2 bins)");
+        return MI_EINVAL;
+    }
+    return launch_sample_pdf(n, n_bins, n_samples, bins, weights, u_lin, samples, (hipStream_t)stream);
+}
+
 int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine) {
     const int64_t S = (int64_t)n_coarse + n_fine;
     // z_c[n,Nc] raw_c[n,Nc,4] w_c[n,Nc] z_f[n,S] raw_f[n,S,4]; each region 256-byte aligned

@@ -281,6 +281,57 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// sample_pdf as a free-standing function (render.py:27-56) on arbitrary per-ray bins: one wave per ray,
+// same arithmetic as sample_fine_kernel without the merge.  bins [n,nb], weights [n,nb-1] -> out [n,ns].
+// LDS per wave: cdf[nb] | pdf[nb]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_pdf_kernel(int64_t n, int nb, int ns, const float* __restrict__ bins,
+                                                         const float* __restrict__ weights,
+                                                         const float* __restrict__ u_lin, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* cdf = smem + wave * 2 * nb;
+    float* pdf = cdf + nb;
+    const int nw = nb - 1;
+    for (int64_t ray = (int64_t)blockIdx.x * 4 + wave; ray < n; ray += (int64_t)gridDim.x * 4) {
+        const float* wr = weights + ray * nw;
+        const float* br = bins + ray * nb;
+        float part = 0.f;
+        for (int j = lane; j < nw; j += 64) part += wr[j] + 1e-5f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        for (int j = lane; j < nw; j += 64) pdf[j] = (wr[j] + 1e-5f) / part;
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int j = lane; j < nb; j += 64) {
+            double s = 0.0;
+            for (int i = 0; i < j; ++i) s += (double)pdf[i];
+            cdf[j] = (float)s;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int s = lane; s < ns; s += 64) {
+            const float u = u_lin ? u_lin[s] : linspace_at(0.f, 1.f, ns, s);
+            int lo_i = 0, hi_i = nb;
+            while (lo_i < hi_i) {
+                const int mid = (lo_i + hi_i) >> 1;
+                if (cdf[mid] <= u) lo_i = mid + 1; else hi_i = mid;
+            }
+            const int below = lo_i - 1 > 0 ? lo_i - 1 : 0;
+            const int above = lo_i < nb - 1 ? lo_i : nb - 1;
+            const float c0 = cdf[below], c1 = cdf[above];
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.f;
+            const float t = (u - c0) / denom;
+            const float b0 = br[below], b1 = br[above];
+            out[ray * ns + s] = b0 + t * (b1 - b0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // ---- host launchers ------------------------------------------------------------------------
 int launch_gen_rays(int width, int height, double focal, const float* c2w, int64_t ray0, int64_t n, float* rays,
                     int compute_f64, hipStream_t stream) {
@@ -328,6 +379,18 @@ int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, con
     hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, S, raw, z,
                        rays, g_rgb, g_depth, g_acc, g_raw);
     return check_launch("composite_bwd");
+}
+
+int launch_sample_pdf(int64_t n, int nb, int ns, const float* bins, const float* weights, const float* u_lin, float* out,
+                      hipStream_t stream) {
+    if (n <= 0 || ns <= 0) return 0;
+    const size_t lds = (size_t)4 * 2 * nb * sizeof(float);
+    if (lds > 160 * 1024) { set_error("sample_pdf: %d bins exceed LDS", nb); return -1; }
+    int64_t blocks = (n + 3) / 4;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, n, nb, ns, bins, weights, u_lin,
+                       out);
+    return check_launch("sample_pdf");
 }
 
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,

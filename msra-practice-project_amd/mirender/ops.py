@@ -102,6 +102,22 @@ def sample_fine(z_coarse: torch.Tensor, weights: torch.Tensor, near: float, far:
     return (z_fine, zs) if want_samples else z_fine
 
 
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int) -> torch.Tensor:
+    """sample_pdf(bins[n,nb], weights[n,nb-1], N) -> [n,N] (render.py:27-56), any bins."""
+    lib = _lib.load()
+    dev = bins.device
+    bins, weights = _f32c(bins, dev), _f32c(weights, dev)
+    n, nb = bins.shape
+    if tuple(weights.shape) != (n, nb - 1):
+        raise _lib.MiRenderError("weights must be [n, len(bins)-1]")
+    out = torch.empty((n, n_samples), dtype=torch.float32, device=dev)
+    ul = linspace_table(0.0, 1.0, n_samples, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_sample_pdf(n, nb, n_samples, _lib.ptr(bins), _lib.ptr(weights), _lib.ptr(ul), _lib.ptr(out),
+                                     _lib.stream_ptr(dev)), "mi_sample_pdf")
+    return out
+
+
 def _film_for(pf: PackedField, film, n_rays):
     if not is_film(pf.kind):
         return None, 1, n_rays

@@ -57,9 +57,9 @@ def get_rays(width, height, focal, c2w):
 
 
 def sample_pdf(bins, weights, N_samples):
-    """nerf/render.py:27-56 is only ever called as sample_pdf(mids, weights[...,1:-1], Nf) (render.py:140);
-    the kernel implements that call.  Exposed for star-import compatibility."""
-    raise _lib.MiRenderError("sample_pdf is fused into mirender.ops.sample_fine (takes z_coarse and weights)")
+    """nerf/render.py:27-56: inverse-CDF samples [N, N_samples] from per-ray bins [N,nb] and weights [N,nb-1]."""
+    dev = bins.device if isinstance(bins, torch.Tensor) and bins.is_cuda else _device_of()
+    return ops.sample_pdf(torch.as_tensor(bins).to(dev), torch.as_tensor(weights).to(dev), int(N_samples))
 
 
 def run_network(ray_samples, view_dirs, network, chunk=1024 * 64):

@@ -206,6 +206,23 @@ def _check_fine(zs, zf, ref_s, ref_f, bins, w_interior, nf):
     return float((mask & (d > tol)).mean())                  # samples that really took the other branch
 
 
+def test_sample_pdf_golden(mi, golden):
+    """Fixture F3 exactly as the reference produced it: sample_pdf(bins, weights, N) on arbitrary bins,
+    all-zero weights, a single spike, two-ended mass, tiny mass, uniform; N in {0, 1, 24, 128}."""
+    g = golden("pdf_f3")
+    for bins_k, w_k, outs in (("bins", "weights", {0: "samples_0", 1: "samples_1", 24: "samples_24", 128: "samples_128"}),
+                              ("bins11", "weights11", {24: "samples11_24"})):
+        for ns, key in outs.items():
+            got = mi.ops.sample_pdf(to_dev(g[bins_k]), to_dev(g[w_k]), ns)
+            assert tuple(got.shape) == g[key].shape
+            if ns == 0:
+                continue
+            mask, tol = _pdf_conditioning(g[bins_k], g[w_k], ns)
+            d = np.abs(got.cpu().numpy().astype(np.float64) - g[key])
+            bad = (d > tol) & ~mask
+            assert not bad.any(), (key, d[bad].max())
+
+
 def test_sample_fine_golden_pdf(mi, golden):
     """sample_pdf edge cases of fixture F3 (all-zero weights, single spike, two-ended mass, tiny mass,
     uniform) through the only call shape the path uses (render.py:140: bins = mids of the coarse
