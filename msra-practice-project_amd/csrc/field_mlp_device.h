@@ -296,29 +296,36 @@ __device__ __forceinline__ float head_dot(const f32x16 (&X)[8], const float* aux
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v)); }
 
-// Positional-encoding blocks through an LDS scratch so sincosf is not inlined per register.
-// Feature f of the encoding of (x,y,z) with L frequencies: i=f/6, c=f%6: c<3 sin(2^i x_c) else cos(2^i x_{c-3}).
+// Positional-encoding blocks, fully unrolled.  Feature f of the encoding of (x,y,z): i = f/6, c = f%6,
+// c < 3 -> sin(2^i x_c), else cos(2^i x_{c-3}) (nerf/nerf.py:44-49).  Register r of block blk holds feature
+// f0 = 32 blk + (r&3) + 8 (r>>2) on lane half 0 and f0 + 4 on half 1, so (frequency, component, sin|cos) are
+// compile-time constants per half and only a select on h remains at run time.  One v_sin per feature:
+// the argument goes to revolutions with a two-float product (as hw_sincos) and cos is sin shifted by 1/4 turn.
+__device__ __forceinline__ float pe_feature(float xv, float scale, float quarter) {
+    const float c_hi = 0.15915494309189535f;                                    // 1 / (2 pi)
+    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    const float a = xv * scale;                                                 // exact: scale is a power of two
+    const float hi = a * c_hi;
+    const float lo = fmaf(a, c_hi, -hi) + a * c_lo;
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(hi) + lo + quarter);
+}
+
 template <int NBLK>
-__device__ __forceinline__ void posenc_blocks(float* scr, int lane, int h, float x, float y, float z, int nfeat,
+__device__ __forceinline__ void posenc_blocks(float* /*scr*/, int /*lane*/, int h, float x, float y, float z, int nfeat,
                                               f32x16* out) {
-#pragma unroll 1
-    for (int slot = 0; slot < NBLK * 16; ++slot) {
-        const int r = slot & 15, blk = slot >> 4;
-        const int f = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * h;
-        float v = 0.f;
-        if (f < nfeat) {
-            const int i = f / 6, cc = f - 6 * i;
-            const int comp = cc >= 3 ? cc - 3 : cc;
-            const float xv = comp == 0 ? x : (comp == 1 ? y : z);
-            const SinCos sc = hw_sincos(ldexpf(xv, i));
-            v = cc >= 3 ? sc.c : sc.s;
-        }
-        scr[slot * 64 + lane] = v;
-    }
-#pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[blk][r] = scr[(blk * 16 + r) * 64 + lane];
+    const float xyz[3] = {x, y, z};
+    static_for<NBLK * 16>([&](auto sc) {
+        constexpr int slot = decltype(sc)::value;
+        constexpr int r = slot & 15, blk = slot >> 4;
+        constexpr int f0 = 32 * blk + (r & 3) + 8 * (r >> 2), f1 = f0 + 4;
+        constexpr int i0 = f0 / 6, c0 = f0 % 6, i1 = f1 / 6, c1 = f1 % 6;
+        const bool up = h != 0;
+        const int f = up ? f1 : f0;
+        const float xv = up ? xyz[c1 % 3] : xyz[c0 % 3];
+        const float scale = up ? (float)(1 << i1) : (float)(1 << i0);
+        const float quarter = up ? (c1 >= 3 ? 0.25f : 0.f) : (c0 >= 3 ? 0.25f : 0.f);
+        out[blk][r] = f < nfeat ? pe_feature(xv, scale, quarter) : 0.f;
+    });
 }
 
 struct PointIn {

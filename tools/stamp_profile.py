@@ -57,11 +57,5 @@ for i in range(1, 22):
         acc_mfma += d; acc_ideal += ideal[i]
     print(f"{i:2d} {names[i]:32s} {d:9.0f}  {100 * d / total:5.1f} %{extra}")
 print(f"mfma phases {acc_mfma:.0f} vs ideal {acc_ideal} -> {100 * acc_ideal / acc_mfma:.1f} % ; non-mfma phases {total - acc_mfma:.0f} ({100 * (total - acc_mfma) / total:.1f} %)")
-b = body
-print("one mid-kernel K-block stage (stage 40 = a 256x256 layer's block), median cycles:")
-for lo, hi, nm in ((22, 23, "end of previous block -> own DMA landed (vmcnt 0)"), (23, 24, "barrier (wait for the other 3 waves)"),
-                   (24, 25, "first row: 8 ds_read + 32 MFMA issued"), (25, 26, "issue next block's DMA (8 pieces)"),
-                   (26, 27, "remaining 3 rows (96 MFMA)"), (22, 27, "whole stage incl. barrier (ideal 8192)")):
-    print(f"   {nm:55s} {np.median(b[:, hi] - b[:, lo]):8.0f}")
 gaps = np.median(s[768:, 0] - s[512:-256, 21])    # start of a tile vs end of the tile 256 workgroups earlier (same CU, roughly)
 print(f"approx. workgroup turnaround on a CU: {gaps:.0f}")
