@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx(smem, a, group);
     MI_STAMP(a, 0);
-    issue_stage<1, 32, false>(c, 0, 0, 0);   // layer 0: bias + K block 0 (PE features 0..31)
+    issue_first_stage<1, 32, false>(c, 0, 0, 0);   // layer 0: bias + K block 0 (PE features 0..31)
 
     const PointIn pt = load_point(a.mode, a.a, a.z, group, a.points_per_group, a.rays_per_group, a.n_samples,
                                   tile * 128 + c.wave * 32 + (c.lane & 31));
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx(smem, a, group);
-    issue_stage<4, 0, false>(c, 0, 0, 0);   // layers_pos[0]: bias + 3 weight columns (K = 3, VALU)
+    issue_first_stage<4, 0, false>(c, 0, 0, 0);   // layers_pos[0]: bias + 3 weight columns (K = 3, VALU)
 
     const PointIn pt = load_point(a.mode, a.a, a.z, group, a.points_per_group, a.rays_per_group, a.n_samples,
                                   tile * 128 + c.wave * 32 + (c.lane & 31));
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
 
     int slot = 0;
     __syncthreads();
-    issue_stage<1, 32, false>(c, 1, 0, 0);
+    issue_first_stage<1, 32, false>(c, 1, 0, 0);
     init_acc<8, true>(smem + kLdsAux0, c.h, 1, pt.px, pt.py, pt.pz, acc);
     sin_act(1); slot ^= 1;
 #pragma unroll 1
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx(smem, a, group);
-    issue_stage<4, 0, true>(c, 0, 0, 0);   // input_layer: bias + 3 columns, FiLM row 0
+    issue_first_stage<4, 0, true>(c, 0, 0, 0);   // input_layer: bias + 3 columns, FiLM row 0
 
     const PointIn pt = load_point(a.mode, a.a, a.z, group, a.points_per_group, a.rays_per_group, a.n_samples,
                                   tile * 128 + c.wave * 32 + (c.lane & 31));
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
 
     int slot = 0;
     __syncthreads();
-    issue_stage<1, 32, true>(c, 1, 0, 1);
+    issue_first_stage<1, 32, true>(c, 1, 0, 1);
     init_acc<8, true>(smem + kLdsAux0, c.h, 1, pt.px, pt.py, pt.pz, acc);
     film_act(0, 0); slot ^= 1;
 #pragma unroll 1

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     constexpr RegionLayout GL = TINY ? tiny_grads() : nerf_grads();
     constexpr int kHeadAux = TINY ? 4 : 3;                 // rgb rows (+ sigma row for TinyNeRF)
     const int64_t P = a.points;
-    issue_stage<kHeadAux, 32, false>(c, 0, 0, 0);
+    issue_first_stage<kHeadAux, 32, false>(c, 0, 0, 0);
 
     const int64_t local = (int64_t)blockIdx.x * 128 + c.wave * 32 + (c.lane & 31);
     const bool valid = local < P;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     constexpr RegionLayout AL = siren_acts();
     constexpr RegionLayout GL = siren_grads();
     const int64_t P = a.points;
-    issue_stage<3, 32, false>(c, 0, 0, 0);
+    issue_first_stage<3, 32, false>(c, 0, 0, 0);
 
     const int64_t local = (int64_t)blockIdx.x * 128 + c.wave * 32 + (c.lane & 31);
     const bool valid = local < P;
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     Ctx c = make_ctx_raw(smem, a.packed, nullptr);
     const int64_t P = a.points;
-    issue_stage<4, 32, false>(c, 0, 0, 0);                 // rgb head rows x3, sigma row; K block 0 of hidden_layer_rgb^T
+    issue_first_stage<4, 32, false>(c, 0, 0, 0);                 // rgb head rows x3, sigma row; K block 0 of hidden_layer_rgb^T
 
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;

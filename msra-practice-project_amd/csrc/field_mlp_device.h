@@ -27,12 +27,12 @@ __device__ __forceinline__ lds4_t lds_base(const float* p) {
 }
 
 // ---- LDS map (floats) ----------------------------------------------------------------------
-constexpr int kLdsChunk = 8192;                          // 32 KiB K-block buffer (MB = 8)
+constexpr int kLdsChunk = 16384;                         // 64 KiB stage buffer = two 32-wide K blocks (MB = 8)
 constexpr int kLdsAux = kMaxAuxPieces * kPiece;          // 8 KiB per-layer aux slot
 constexpr int kLdsChunk0 = 0;
 constexpr int kLdsAux0 = 2 * kLdsChunk;
 constexpr int kLdsFilm0 = kLdsAux0 + 2 * kLdsAux;
-constexpr int kLdsFloats = kLdsFilm0 + 2 * kFilmRow;     // 21504 floats = 84 KiB
+constexpr int kLdsFloats = kLdsFilm0 + 2 * kFilmRow;     // 37888 floats = 148 KiB of the CU's 160 KiB
 
 enum Act : int { ACT_LINEAR = 0, ACT_RELU = 1, ACT_SIN30 = 2, ACT_FILM = 3 };
 
@@ -41,6 +41,7 @@ struct Ctx {
     __amdgpu_buffer_rsrc_t rsrc;    // buffer descriptor of the packed weight stream
     __amdgpu_buffer_rsrc_t frsrc;   // ... of this group's FiLM table [9][512] (FiLM kinds)
     int soff;                       // byte offset of the next unread piece of the stream (wave-uniform, SGPR)
+    int buf;                        // stage buffer (0/1) holding the next stage to consume
     int voff;                       // per-lane byte offset inside a round of 4 pieces: wave * 1024 + lane * 16
     int lane, wave, h;
 #ifdef MI_PROFILE_STAMPS
@@ -82,6 +83,13 @@ __device__ __forceinline__ void issue_stage(Ctx& c, int aux_slot, int chunk_buf,
         dma_lump<N_CHUNK_PIECES>(c, c.rsrc, c.soff, kLdsChunk0 + chunk_buf * kLdsChunk);
         c.soff += N_CHUNK_PIECES * 1024;
     }
+}
+
+// First stage of a layer, issued in one go (kernel start, or after a VALU-only first layer): its aux pieces and
+// its first TWO K blocks (every MFMA layer has at least two) into the current stage buffer.
+template <int N_AUX, int BLOCK_PIECES, bool FILM>
+__device__ __forceinline__ void issue_first_stage(Ctx& c, int aux_slot, int /*unused*/, int film_layer) {
+    issue_stage<N_AUX, 2 * BLOCK_PIECES, FILM>(c, aux_slot, c.buf, film_layer);
 }
 
 // The same stage issued piecewise from NSLOT call sites spread over a K block's first row of MFMAs:
@@ -226,21 +234,32 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 // On entry the layer's first stage (aux + K block 0) has been issued into aux slot
 // `aux_slot` and chunk buffer PAR0.  NEXT_* describe the stage to issue while the last K block
 // computes (the next layer's first stage), 0/0 for none.
-template <int KB, int MB, int PAR0, int NEXT_AUX, int NEXT_CHUNK, bool FILM, class Init, class BSel>
+// A stage = up to two K blocks behind one barrier (39 barriers per NeRF tile instead of 77).  Stage buffers
+// alternate (c.buf); while stage i computes, stage i+1's pieces (or the next layer's aux pieces + its first
+// two K blocks: NEXT_AUX, NEXT_BLOCK = pieces of one of its K blocks, 0 for none) are DMA'd into the other one.
+template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, class Init, class BSel>
 __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film_layer, Init init, BSel bsel,
                                              f32x16 (&acc)[8]) {
-    auto stage = [&](auto kbc) {
-        constexpr int kb = decltype(kbc)::value;
-        constexpr int cur = (PAR0 + kb) & 1;
+    static_assert(KB >= 2, "every MFMA layer has at least two K blocks");
+    auto stage = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int kb0 = 2 * i;
+        constexpr bool two = kb0 + 1 < KB;
+        constexpr int left = KB - 2 * (i + 1);                       // K blocks after this stage
+        constexpr int next_blocks = left >= 2 ? 2 : (left > 0 ? left : 0);
         __syncthreads();
-        if constexpr (kb == 0) init(acc);
-        mma_chunk<MB>(c.smem + kLdsChunk0 + cur * kLdsChunk, c.lane, bsel(kbc), acc, [&](auto sc) {
+        if constexpr (i == 0) init(acc);
+        const float* buf = c.smem + kLdsChunk0 + c.buf * kLdsChunk;
+        mma_chunk<MB>(buf, c.lane, bsel(std::integral_constant<int, kb0>{}), acc, [&](auto sc) {
             constexpr int S = decltype(sc)::value;
-            if constexpr (kb + 1 < KB) issue_stage_slot<0, MB * 4, false, MB, S>(c, 0, cur ^ 1, 0);
-            else issue_stage_slot<NEXT_AUX, NEXT_CHUNK, FILM, MB, S>(c, aux_slot ^ 1, cur ^ 1, next_film_layer);
+            if constexpr (next_blocks > 0) issue_stage_slot<0, next_blocks * MB * 4, false, MB, S>(c, 0, c.buf ^ 1, 0);
+            else issue_stage_slot<NEXT_AUX, 2 * NEXT_BLOCK, FILM, MB, S>(c, aux_slot ^ 1, c.buf ^ 1, next_film_layer);
         });
+        if constexpr (two)
+            mma_chunk<MB>(buf + MB * 1024, c.lane, bsel(std::integral_constant<int, kb0 + 1>{}), acc, [](auto) {});
+        c.buf ^= 1;
     };
-    static_for<KB>(stage);
+    static_for<(KB + 1) / 2>(stage);
 }
 
 // forward flavour: accumulators start from the bias (+ the K=3 input columns) held in the layer's aux slot
@@ -369,6 +388,7 @@ __device__ __forceinline__ Ctx make_ctx_raw(float* smem, const float* packed, co
     c.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)packed, 0, 0x7fffffff, 0x00020000);
     c.frsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(film_group ? film_group : packed), 0, 0x7fffffff, 0x00020000);
     c.soff = 0;
+    c.buf = 0;
     c.voff = c.wave * 1024 + c.lane * 16;
 #ifdef MI_PROFILE_STAMPS
     c.stamps = nullptr;
