@@ -114,12 +114,9 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
 
     constexpr RegionLayout RL = TINY ? tiny_acts() : nerf_acts();
     const int64_t SP = a.save_points;
-    const auto save = [&](int off_floats_per_point, int width, auto mbc, const f32x16 (&blk)[8]) {
-        if constexpr (SAVE)
-            store_rows<decltype(mbc)::value>(a.save + (int64_t)off_floats_per_point * SP, width, pt.p, pt.valid, c.h, blk);
+    const auto rows = [&](int off_floats_per_point, int width) {
+        return SaveRows{nullptr, SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, nullptr, width, pt.p, pt.valid};
     };
-    using MB8 = std::integral_constant<int, 8>;
-    using MB4 = std::integral_constant<int, 4>;
     if constexpr (SAVE) {
         f32x16 tmp[8];
         tmp[0] = pe[0]; tmp[1] = pe[1];
@@ -142,39 +139,32 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     int slot = 0;
     MI_STAMP(a, 1);
     // layers_pos[0]: 60 -> 256
-    mma_layer<2, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc);
-    MI_STAMP(a, 2);
-    activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
+    fwd_layer<2, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc, X, nullptr, rows(64, 256));
+    slot ^= 1;                                                          // H1
     MI_STAMP(a, 3);
-    save(64, 256, MB8{}, X);                                            // H1
     float sigma;
     if constexpr (!TINY) {
         // layers_pos[1..4]
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
-            mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-            MI_STAMP(a, 2 + 2 * l);
-            activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
-            save(64 + 256 * l, 256, MB8{}, X);                          // H2..H5
+            fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                 rows(64 + 256 * l, 256));   // H2..H5
+            slot ^= 1;
             MI_STAMP(a, 3 + 2 * l);
         }
         // layers_pos[5]: [PE(60) | h(256)] -> 256
-        mma_layer<10, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_skip, acc);
-        MI_STAMP(a, 12);
-        activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
+        fwd_layer<10, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_skip, acc, X, nullptr,
+                                                              rows(region_offset(RL, 6), 256));   // H6
+        slot ^= 1;
         MI_STAMP(a, 13);
-        save(region_offset(RL, 6), 256, MB8{}, X);                      // H6
         // layers_pos[6]
-        mma_layer<8, 8, 0, false, 3, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        MI_STAMP(a, 14);
-        activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
-        save(region_offset(RL, 7), 256, MB8{}, X);                      // H7
+        fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                             rows(region_offset(RL, 7), 256));    // H7
+        slot ^= 1;
         MI_STAMP(a, 15);
         // layers_pos[7] (+ sigma head pieces)
-        mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        MI_STAMP(a, 16);
-        activate<8, ACT_RELU>(acc, X, nullptr, c.h);
-        save(region_offset(RL, 8), 256, MB8{}, X);                      // H8
+        fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                             rows(region_offset(RL, 8), 256));    // H8
         {
             const float* aux = smem + kLdsAux0 + slot * kLdsAux;
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
@@ -182,22 +172,20 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
         slot ^= 1;
         MI_STAMP(a, 17);
         // layers_dir[0]: linear
-        mma_layer<8, 8, 0, false, 5, 16, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        MI_STAMP(a, 18);
-        activate<8, ACT_LINEAR>(acc, X, nullptr, c.h); slot ^= 1;
+        fwd_layer<8, 8, false, 5, 16, false, ACT_LINEAR, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                               rows(region_offset(RL, 9), 256));  // G
+        slot ^= 1;
         MI_STAMP(a, 19);
-        save(region_offset(RL, 9), 256, MB8{}, X);                      // G
     } else {
         // layers_pos[1], [2], [3] (+ sigma head pieces), then the dir layer's 5 aux pieces
-        mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
-        save(region_offset(RL, 2), 256, MB8{}, X);
-        mma_layer<8, 8, 0, false, 3, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        activate<8, ACT_RELU>(acc, X, nullptr, c.h); slot ^= 1;
-        save(region_offset(RL, 3), 256, MB8{}, X);
-        mma_layer<8, 8, 0, false, 5, 16, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        activate<8, ACT_RELU>(acc, X, nullptr, c.h);
-        save(region_offset(RL, 4), 256, MB8{}, X);
+        fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                             rows(region_offset(RL, 2), 256));
+        slot ^= 1;
+        fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                             rows(region_offset(RL, 3), 256));
+        slot ^= 1;
+        fwd_layer<8, 8, false, 5, 16, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                             rows(region_offset(RL, 4), 256));
         {
             const float* aux = smem + kLdsAux0 + slot * kLdsAux;
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
@@ -205,10 +193,9 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
         slot ^= 1;
     }
     // layers_dir[1] (TinyNeRF: layers_dir[0]): [h(256) | PE_dir(24)] -> 128, relu; then rgb head
-    mma_layer<9, 4, 0, false, 0, 0, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_dir, acc);
+    fwd_layer<9, 4, false, 0, 0, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_dir, acc, X, nullptr,
+                                                        rows(region_offset(RL, TINY ? 6 : 11), 128));   // H_d
     MI_STAMP(a, 20);
-    activate<4, ACT_RELU>(acc, X, nullptr, c.h);
-    save(region_offset(RL, TINY ? 6 : 11), 128, MB4{}, X);              // H_d
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 1, c.h) + aux[4 * kPiece + 0]);
     const float g = sigmoidf(head_dot<4>(X, aux, 2, c.h) + aux[4 * kPiece + 1]);
@@ -236,6 +223,10 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     const int64_t SP = a.save_points;
     const auto region = [&](int idx) { return a.save + (int64_t)region_offset(RL, idx) * SP; };
     // sin layer l (1..8): X_l -> region 2l-1, C_l -> region 2l
+    const auto sin_rows = [&](int l) {
+        float* base = SAVE ? a.save + (int64_t)(8 + 512 * (l - 1)) * SP : nullptr;
+        return SaveRows{nullptr, base, SAVE ? base + 256 * SP : nullptr, 256, pt.p, pt.valid};
+    };
     const auto sin_act = [&](int l) {
         if constexpr (SAVE)
             activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, nullptr, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
@@ -258,31 +249,27 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     sin_act(1); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        sin_act(l + 1); slot ^= 1;
+        fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(l + 1));
+        slot ^= 1;
     }
-    mma_layer<8, 8, 0, false, 4, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // layers_pos[4]
-    sin_act(5); slot ^= 1;
-    mma_layer<8, 8, 0, true, 1, 32, false>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc);  // [5]: [pos | h]
-    sin_act(6); slot ^= 1;
-    mma_layer<8, 8, 0, false, 3, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // [6]
-    sin_act(7); slot ^= 1;
-    mma_layer<8, 8, 0, false, 1, 32, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // [7] + sigma head
-    sin_act(8);
+    fwd_layer<8, 8, false, 4, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(5));  // layers_pos[4]
+    slot ^= 1;
+    fwd_layer<8, 8, true, 1, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc, X, nullptr, sin_rows(6));  // [5]: [pos | h]
+    slot ^= 1;
+    fwd_layer<8, 8, false, 3, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(7));  // [6]
+    slot ^= 1;
+    fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(8));  // [7] + sigma head
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
         sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
     }
     slot ^= 1;
-    mma_layer<8, 8, 0, false, 8, 16, false>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc);     // layers_dir[0] linear
-    activate<8, ACT_LINEAR>(acc, X, nullptr, c.h); slot ^= 1;
-    if constexpr (SAVE) store_rows<8>(region(17), 256, pt.p, pt.valid, c.h, X);             // G
-    mma_layer<8, 4, 0, true, 0, 0, false>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc);   // layers_dir[1]: [h | dir]
-    if constexpr (SAVE)
-        activate_train<4, ACT_SIN30>(acc, X, nullptr, c.h, nullptr, region(18), region(19), 128, pt.p, pt.valid);
-    else
-        activate<4, ACT_SIN30>(acc, X, nullptr, c.h);
+    fwd_layer<8, 8, false, 8, 16, false, ACT_LINEAR, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                           SaveRows{nullptr, SAVE ? region(17) : nullptr, nullptr, 256, pt.p, pt.valid});  // layers_dir[0] linear: G
+    slot ^= 1;
+    fwd_layer<8, 4, true, 0, 0, false, ACT_SIN30, SAVE>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, nullptr,
+                                                        SaveRows{nullptr, SAVE ? region(18) : nullptr, SAVE ? region(19) : nullptr, 128, pt.p, pt.valid});  // layers_dir[1]: [h | dir]
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 4, c.h) + aux[7 * kPiece + 0]);
     const float g = sigmoidf(head_dot<4>(X, aux, 5, c.h) + aux[7 * kPiece + 1]);
@@ -309,6 +296,10 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const auto film_row = [&](int s) { return smem + kLdsFilm0 + s * kFilmRow; };
     const int64_t SP = a.save_points;
     // FiLM layer l (0..8): A_l -> region 1+3l, X_l -> 2+3l, C_l -> 3+3l (each 256 wide, after the 8-wide xin)
+    const auto film_rows = [&](int l) {
+        float* base = SAVE ? a.save + (int64_t)(8 + 768 * l) * SP : nullptr;
+        return SaveRows{base, SAVE ? base + 256 * SP : nullptr, SAVE ? base + 512 * SP : nullptr, 256, pt.p, pt.valid};
+    };
     const auto film_act = [&](int l, int slot_) {
         if constexpr (SAVE) {
             float* base = a.save + (int64_t)(8 + 768 * l) * SP;
@@ -333,21 +324,19 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     film_act(0, 0); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 5; ++l) {                                                   // hidden_layers[0..4]
-        mma_layer<8, 8, 0, false, 1, 32, true>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc);
-        film_act(l, slot); slot ^= 1;
+        fwd_layer<8, 8, false, 1, 32, true, ACT_FILM, SAVE>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(l));
+        slot ^= 1;
     }
-    mma_layer<8, 8, 0, false, 3, 32, true>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc);  // hidden_layers[5]
-    film_act(6, slot); slot ^= 1;
-    mma_layer<8, 8, 0, false, USE_DIR ? 8 : 5, 32, true>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc);  // hidden_layers[6]
-    film_act(7, slot);
+    fwd_layer<8, 8, false, 3, 32, true, ACT_FILM, SAVE>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(6));  // hidden_layers[5]
+    slot ^= 1;
+    fwd_layer<8, 8, false, USE_DIR ? 8 : 5, 32, true, ACT_FILM, SAVE>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(7));  // hidden_layers[6]
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
         sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
     }
     slot ^= 1;
-    mma_layer<8, 8, 0, USE_DIR, 0, 0, false>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc);   // hidden_layer_rgb
-    film_act(8, slot);
+    fwd_layer<8, 8, USE_DIR, 0, 0, false, ACT_FILM, SAVE>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, film_row(slot), film_rows(8));   // hidden_layer_rgb
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     constexpr int hp = USE_DIR ? 4 : 1;
     const float r = sigmoidf(head_dot<8>(X, aux, hp + 0, c.h) + aux[(hp + 3) * kPiece + 0]);

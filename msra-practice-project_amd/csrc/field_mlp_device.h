@@ -109,34 +109,72 @@ __device__ __forceinline__ void issue_stage_slot(Ctx& c, int aux_slot, int chunk
     if constexpr (S == NSLOT - 1) c.soff += N_CHUNK_PIECES * 1024;
 }
 
-// One row of fragments (all MB output blocks of one rg) is read first, then its 4*MB MFMAs are issued q-major
-// so consecutive MFMAs hit MB different accumulators.  MFMA issue is in-order and blocking, so anything the
-// wave issues in one lump between two MFMAs idles the matrix pipe for its whole issue time (measured: 416
-// cycles for a lump of 8 DMA pieces).  The next stage's DMA is therefore issued piecewise: `slot(s)` is
-// called after every 4th MFMA of the first row (s = 0..MB-1), pinned there by sched_barrier.
-template <int MB, class Slot>
-__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8], Slot slot) {
+// One row of fragments (all MB output blocks of one rg) is read first, then its 4*MB MFMAs are issued.
+// MFMA issue is in-order and blocking, so anything the wave issues in one lump between two MFMAs idles the
+// matrix pipe for its whole issue time (measured: 416 cycles for a lump of 8 DMA pieces, ~2.5 k cycles per
+// layer for the bias preload + activation lumps).  Everything else is therefore sliced and pinned between
+// MFMAs with sched_barrier:
+//   * slot(s), s = 0..MB-1: after every 4th MFMA of the first row - the next stage's DMA pieces;
+//   * ORDER bit 0 (a layer's first K block): the first row runs m-major and pre(m+1, part) - the bias preload
+//     of the NEXT accumulator block, a quarter at a time - sits after each MFMA of block m's chain;
+//   * ORDER bit 1 (a layer's last K block): the last row runs m-major and post(m-1, part) - the activation of
+//     the block whose chain has just completed - rides one MFMA behind (its result lands 64 cycles after issue).
+// Other rows run q-major (MB independent accumulators round-robin).
+struct NoHook {
+    template <class A, class B> __device__ __forceinline__ void operator()(A, B) const {}
+    template <class A> __device__ __forceinline__ void operator()(A) const {}
+};
+template <int I> using ic = std::integral_constant<int, I>;
+
+template <int MB, int ORDER, class Slot, class Pre, class Post>
+__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8], Slot slot,
+                                          Pre pre, Post post) {
     const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + lane;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
+    static_for<4>([&](auto rgc) {
+        constexpr int rg = decltype(rgc)::value;
         f32x4 a[MB];
 #pragma unroll
         for (int m = 0; m < MB; ++m) a[m] = a4[(rg * MB + m) * 64];
-        static_for<4>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            static_for<MB / 4>([&](auto gc) {
-                constexpr int g = decltype(gc)::value;
-#pragma unroll
-                for (int m = 4 * g; m < 4 * g + 4; ++m)
+        constexpr bool first_mm = (ORDER & 1) && rg == 0;
+        constexpr bool last_mm = (ORDER & 2) && rg == 3;
+        if constexpr (first_mm || last_mm) {
+            if constexpr (first_mm) static_for<4>([&](auto pc) { pre(ic<0>{}, pc); });
+            static_for<MB>([&](auto mc) {
+                constexpr int m = decltype(mc)::value;
+                static_for<4>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], acc[m], 0, 0, 0);
-                if (rg == 0) {
                     __builtin_amdgcn_sched_barrier(0);
-                    slot(std::integral_constant<int, q * (MB / 4) + g>{});
+                    if constexpr (first_mm && m + 1 < MB) pre(ic<m + 1>{}, qc);
+                    if constexpr (last_mm) {
+                        if constexpr (q >= 1 && m >= 1) post(ic<m - 1>{}, ic<q - 1>{});
+                        if constexpr (q == 0 && m >= 2) post(ic<m - 2>{}, ic<3>{});
+                    }
+                    if constexpr (rg == 0 && q == 3) slot(ic<m>{});
                     __builtin_amdgcn_sched_barrier(0);
-                }
+                });
             });
-        });
-    }
+            if constexpr (last_mm) {
+                if constexpr (MB >= 2) post(ic<MB - 2>{}, ic<3>{});
+                static_for<4>([&](auto pc) { post(ic<MB - 1>{}, pc); });
+            }
+        } else {
+            static_for<4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                static_for<MB / 4>([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+#pragma unroll
+                    for (int m = 4 * g; m < 4 * g + 4; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], acc[m], 0, 0, 0);
+                    if constexpr (rg == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        slot(ic<q * (MB / 4) + g>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            });
+        }
+    });
 }
 
 // acc = bias (+ W3 * xyz for the K=3 inputs of Siren/FiLM nets), from the layer's aux slot.
@@ -237,26 +275,30 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 // A stage = up to two K blocks behind one barrier (39 barriers per NeRF tile instead of 77).  Stage buffers
 // alternate (c.buf); while stage i computes, stage i+1's pieces (or the next layer's aux pieces + its first
 // two K blocks: NEXT_AUX, NEXT_BLOCK = pieces of one of its K blocks, 0 for none) are DMA'd into the other one.
-template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, class Init, class BSel>
+// HOOKS: pre(m, part) / post(m, part) are the sliced bias preload / activation of mma_chunk; without them
+// init(acc) runs as one lump before the first MFMA and the caller applies its epilogue after the call.
+template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, bool HOOKS = false, class Init,
+          class BSel, class Pre = NoHook, class Post = NoHook>
 __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film_layer, Init init, BSel bsel,
-                                             f32x16 (&acc)[8]) {
+                                             f32x16 (&acc)[8], Pre pre = Pre{}, Post post = Post{}) {
     static_assert(KB >= 2, "every MFMA layer has at least two K blocks");
-    auto stage = [&](auto ic) {
-        constexpr int i = decltype(ic)::value;
+    auto stage = [&](auto ic_) {
+        constexpr int i = decltype(ic_)::value;
         constexpr int kb0 = 2 * i;
         constexpr bool two = kb0 + 1 < KB;
         constexpr int left = KB - 2 * (i + 1);                       // K blocks after this stage
         constexpr int next_blocks = left >= 2 ? 2 : (left > 0 ? left : 0);
+        constexpr int order0 = HOOKS ? ((kb0 == 0 ? 1 : 0) | (kb0 == KB - 1 ? 2 : 0)) : 0;
+        constexpr int order1 = HOOKS ? (kb0 + 1 == KB - 1 ? 2 : 0) : 0;
         __syncthreads();
-        if constexpr (i == 0) init(acc);
+        if constexpr (i == 0 && !HOOKS) init(acc);
         const float* buf = c.smem + kLdsChunk0 + c.buf * kLdsChunk;
-        mma_chunk<MB>(buf, c.lane, bsel(std::integral_constant<int, kb0>{}), acc, [&](auto sc) {
+        mma_chunk<MB, order0>(buf, c.lane, bsel(ic<kb0>{}), acc, [&](auto sc) {
             constexpr int S = decltype(sc)::value;
             if constexpr (next_blocks > 0) issue_stage_slot<0, next_blocks * MB * 4, false, MB, S>(c, 0, c.buf ^ 1, 0);
             else issue_stage_slot<NEXT_AUX, 2 * NEXT_BLOCK, FILM, MB, S>(c, aux_slot ^ 1, c.buf ^ 1, next_film_layer);
-        });
-        if constexpr (two)
-            mma_chunk<MB>(buf + MB * 1024, c.lane, bsel(std::integral_constant<int, kb0 + 1>{}), acc, [](auto) {});
+        }, pre, post);
+        if constexpr (two) mma_chunk<MB, order1>(buf + MB * 1024, c.lane, bsel(ic<kb0 + 1>{}), acc, NoHook{}, pre, post);
         c.buf ^= 1;
     };
     static_for<(KB + 1) / 2>(stage);
@@ -270,6 +312,78 @@ __device__ __forceinline__ void mma_layer(Ctx& c, int aux_slot, int next_film_la
         init_acc<MB, K3>(c.smem + kLdsAux0 + aux_slot * kLdsAux, c.h, k3_piece, x, y, z, a);
     };
     mma_layer_fn<KB, MB, PAR0, NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot, next_film_layer, init, bsel, acc);
+}
+
+// Rows the training forward stores per layer (any may be null): A = linear output (FiLM), X = activation,
+// C = 30 cos(30 u) derivative factor (sin nets); all [point][ld] row-major.
+struct SaveRows {
+    float* a; float* x; float* c;
+    int64_t ld, p;
+    bool valid;
+};
+
+// One forward layer with the bias preload and the activation (+ training stores) sliced between the MFMAs of
+// its first / last K block.  X <- act(W . [inputs] + b); the layer's inputs may be X itself (in place: block m
+// of X is rewritten only after every K block that reads it has been consumed).
+template <int KB, int MB, bool K3, int NEXT_AUX, int NEXT_BLOCK, bool FILM, int ACT, bool SAVE, class BSel>
+__device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_layer, int k3_piece, float x, float y,
+                                          float z, BSel bsel, f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row,
+                                          const SaveRows& sv) {
+    const int h = c.h;
+    const lds4_t pb = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
+    lds4_t pf = nullptr;
+    if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
+    const auto pre = [&](auto mc, auto pc) {
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
+        f32x4 t = pb[m * 8 + rg];
+        if constexpr (K3) {
+            const f32x4 w0 = pb[(k3_piece + 0) * 64 + m * 8 + rg];
+            const f32x4 w1 = pb[(k3_piece + 1) * 64 + m * 8 + rg];
+            const f32x4 w2 = pb[(k3_piece + 2) * 64 + m * 8 + rg];
+            t.x = fmaf(w2.x, z, fmaf(w1.x, y, fmaf(w0.x, x, t.x)));
+            t.y = fmaf(w2.y, z, fmaf(w1.y, y, fmaf(w0.y, x, t.y)));
+            t.z = fmaf(w2.z, z, fmaf(w1.z, y, fmaf(w0.z, x, t.z)));
+            t.w = fmaf(w2.w, z, fmaf(w1.w, y, fmaf(w0.w, x, t.w)));
+        }
+        acc[m][4 * rg + 0] = t.x; acc[m][4 * rg + 1] = t.y; acc[m][4 * rg + 2] = t.z; acc[m][4 * rg + 3] = t.w;
+    };
+    const auto post = [&](auto mc, auto pc) {
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
+        f32x4 g, bb, xo, co, ao;
+        if constexpr (ACT == ACT_FILM) {
+            g = pf[m * 8 + rg * 2];
+            bb = pf[64 + m * 8 + rg * 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = acc[m][4 * rg + q];
+            float o;
+            if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
+            else if constexpr (ACT == ACT_LINEAR) o = v;
+            else {
+                float u = v;
+                if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), bb[q]);
+                if constexpr (SAVE) {
+                    const SinCos sc = hw_sincos30(u);
+                    o = sc.s;
+                    co[q] = 30.f * sc.c;
+                } else {
+                    o = hw_sin30(u);
+                }
+            }
+            X[m][4 * rg + q] = o;
+            xo[q] = o; ao[q] = v;
+        }
+        if constexpr (SAVE) {
+            if (sv.valid) {
+                const int64_t idx = m * 8 + rg * 2;    // float4 index inside the row (h folded into the row pointer)
+                reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[idx] = xo;
+                if constexpr (ACT == ACT_SIN30 || ACT == ACT_FILM) reinterpret_cast<f32x4*>(sv.c + sv.p * sv.ld + 4 * h)[idx] = co;
+                if constexpr (ACT == ACT_FILM) reinterpret_cast<f32x4*>(sv.a + sv.p * sv.ld + 4 * h)[idx] = ao;
+            }
+        }
+    };
+    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
 }
 
 // acc = s * v[f] (v = VEC piece `piece` of an aux slot) or 0: starting values of the backward chain
