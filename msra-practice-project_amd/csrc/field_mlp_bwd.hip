@@ -117,6 +117,50 @@ __device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
         }
 }
 
+
+// One backward-chain layer with everything but the MFMAs sliced between them (mma_chunk's hooks):
+//   pre(m, part)  : accumulator start (0, or s * aux row `piece`) and the global load of the saved row quarter
+//                   the epilogue of this block needs (H for ReLU, C for sin) - issued a whole layer ahead, so its
+//                   latency sits under ~1000 MFMAs instead of stalling the one resident wave per SIMD;
+//   post(m, part) : dA = dX (.) act'(saved), written to HBM and left in X as the next layer's B operand.
+// B operands come from bsel; when the last K block reads X[j] with j < MB-1 pass a copy (post overwrites X[j]).
+enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2 };
+
+template <int KB, int MB, int NEXT_AUX, int NEXT_BLOCK, int EPI, bool SCALED, class BSel>
+__device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float s, BSel bsel, f32x16 (&acc)[8],
+                                          f32x16 (&X)[8], const float* __restrict__ saved, float* __restrict__ dA,
+                                          int64_t ld, int64_t p, bool valid) {
+    const int h = c.h;
+    const lds4_t pv = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
+    const f32x4* srow = reinterpret_cast<const f32x4*>(saved + p * ld + 4 * h);
+    f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
+    f32x4 sv[EPI == EPI_LINEAR ? 1 : MB * 4];
+    const auto pre = [&](auto mc, auto pc) {
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
+        if constexpr (SCALED) {
+            const f32x4 w = pv[piece * 64 + m * 8 + rg];
+            acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
+        } else {
+            acc[m][4 * rg + 0] = 0.f; acc[m][4 * rg + 1] = 0.f; acc[m][4 * rg + 2] = 0.f; acc[m][4 * rg + 3] = 0.f;
+        }
+        if constexpr (EPI != EPI_LINEAR) sv[m * 4 + rg] = srow[m * 8 + rg * 2];
+    };
+    const auto post = [&](auto mc, auto pc) {
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float d = acc[m][4 * rg + q];
+            if constexpr (EPI == EPI_RELU) o[q] = sv[m * 4 + rg][q] > 0.f ? d : 0.f;
+            else if constexpr (EPI == EPI_SIN) o[q] = sv[m * 4 + rg][q] * d;
+            else o[q] = d;
+            X[m][4 * rg + q] = o[q];
+        }
+        if (valid) drow[m * 8 + rg * 2] = o;
+    };
+    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, false, true>(c, aux_slot, 0, NoHook{}, bsel, acc, pre, post);
+}
+
 // =========================================================================================
 // NeRF / TinyNeRF backward chain (reverse of nerf/nerf.py:75-94)
 // =========================================================================================
@@ -164,44 +208,35 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
 
     int slot = 0;
     if constexpr (!TINY) {
-        // layers_dir[1]^T: dG = W[:, :256]^T dA (K = 128)
-        mma_layer_fn<4, 8, 0, 1, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);
-        slot ^= 1;
-        // layers_dir[0] is linear: dA = dG
+        // layers_dir[1]^T: dG = W[:, :256]^T dA (K = 128); layers_dir[0] is linear: dA = dG.  The B operand is a
+        // copy: the epilogue rewrites X[0..3] while the last K block still reads X[3].
+        f32x16 Bd[4];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) X[m] = acc[m];
-        store_rows<8>(grads(8), 256, p, valid, c.h, X);
-        // layers_dir[0]^T, plus the sigma head's contribution to dH8
-        mma_layer_fn<8, 8, 0, 0, 32, false>(
-            c, slot, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0 + slot * kLdsAux, 0, c.h, ds, x); },
-            sel_x, acc);
+        for (int m = 0; m < 4; ++m) Bd[m] = X[m];
+        const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
+        bwd_layer<4, 8, 1, 32, EPI_LINEAR, false>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
         slot ^= 1;
-        relu_bwd_store<8>(acc, X, acts(8), grads(7), 256, p, valid, c.h);                     // dA7 = dH8 (.) [H8>0]
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L7^T
-        relu_bwd_store<8>(acc, X, acts(7), grads(6), 256, p, valid, c.h);
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L6^T
-        relu_bwd_store<8>(acc, X, acts(6), grads(5), 256, p, valid, c.h);
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L5^T (h part)
-        relu_bwd_store<8>(acc, X, acts(5), grads(4), 256, p, valid, c.h);
+        // layers_dir[0]^T, plus the sigma head's contribution to dH8; dA7 = dH8 (.) [H8>0]
+        bwd_layer<8, 8, 0, 32, EPI_RELU, true>(c, slot, 0, ds, sel_x, acc, X, acts(8), grads(7), 256, p, valid);
+        slot ^= 1;
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(7), grads(6), 256, p, valid);  // L7^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(6), grads(5), 256, p, valid);  // L6^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(5), grads(4), 256, p, valid);  // L5^T (h part)
 #pragma unroll 1
-        for (int l = 4; l >= 2; --l) {                                                         // L4^T .. L2^T
-            mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);
-            relu_bwd_store<8>(acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
-                              a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, c.h);
-        }
-        mma_layer_fn<8, 8, 0, 0, 0, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);   // L1^T
-        relu_bwd_store<8>(acc, X, acts(1), grads(0), 256, p, valid, c.h);
+        for (int l = 4; l >= 2; --l)                                                           // L4^T .. L2^T
+            bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
+                                                    a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid);
+        bwd_layer<8, 8, 0, 0, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid);   // L1^T
     } else {
         // dir layer^T with the sigma head's contribution to dH4 (sigma row is aux piece 3 of slot 0)
-        mma_layer_fn<4, 8, 0, 0, 32, false>(
-            c, slot, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0, 3, c.h, ds, x); }, sel_x, acc);
-        relu_bwd_store<8>(acc, X, acts(4), grads(3), 256, p, valid, c.h);
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L3^T
-        relu_bwd_store<8>(acc, X, acts(3), grads(2), 256, p, valid, c.h);
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);  // L2^T
-        relu_bwd_store<8>(acc, X, acts(2), grads(1), 256, p, valid, c.h);
-        mma_layer_fn<8, 8, 0, 0, 0, false>(c, slot, 0, [&](f32x16 (&x)[8]) { init_zero<8>(x); }, sel_x, acc);   // L1^T
-        relu_bwd_store<8>(acc, X, acts(1), grads(0), 256, p, valid, c.h);
+        f32x16 Bd[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) Bd[m] = X[m];
+        const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
+        bwd_layer<4, 8, 0, 32, EPI_RELU, true>(c, 0, 3, ds, sel_d, acc, X, acts(4), grads(3), 256, p, valid);
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(3), grads(2), 256, p, valid);  // L3^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(1), 256, p, valid);  // L2^T
+        bwd_layer<8, 8, 0, 0, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid);   // L1^T
     }
 }
 
@@ -267,23 +302,21 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     }
     sin_bwd_store<4>(acc, X, acts(19), grads(9), 128, p, valid, c.h);                          // dA layers_dir.1
     int slot = 0;
-    mma_layer_fn<4, 8, 0, 1, 32, false>(c, slot, 0, zero, sel_x, acc);                          // layers_dir.1^T (h part)
-    slot ^= 1;
+    {   // layers_dir.1^T (h part); layers_dir.0 is linear: dA = dG.  B operand copied (see nerf_bwd_kernel).
+        f32x16 Bd[4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) X[m] = acc[m];                                                  // layers_dir.0 is linear
-    store_rows<8>(grads(8), 256, p, valid, c.h, X);
-    mma_layer_fn<8, 8, 0, 0, 32, false>(
-        c, slot, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0 + slot * kLdsAux, 0, c.h, ds, x); }, sel_x,
-        acc);                                                                                   // layers_dir.0^T + sigma head
-    sin_bwd_store<8>(acc, X, acts(16), grads(7), 256, p, valid, c.h);                          // dA7 = dX8 (.) C8
-#pragma unroll 1
-    for (int l = 7; l >= 2; --l) {                                                              // L7^T .. L2^T
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, slot, 0, zero, sel_x, acc);
-        sin_bwd_store<8>(acc, X, a.acts + (int64_t)(8 + 512 * (l - 1) + 256) * P, a.grads + (int64_t)(256 * (l - 1)) * P,
-                         256, p, valid, c.h);                                                   // dA_{l-1} = dX_l (.) C_l
+        for (int m = 0; m < 4; ++m) Bd[m] = X[m];
+        const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
+        bwd_layer<4, 8, 1, 32, EPI_LINEAR, false>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
     }
-    mma_layer_fn<8, 8, 0, 0, 0, false>(c, slot, 0, zero, sel_x, acc);                           // L1^T
-    sin_bwd_store<8>(acc, X, acts(2), grads(0), 256, p, valid, c.h);                           // dA0 = dX1 (.) C1
+    slot ^= 1;
+    // layers_dir.0^T + sigma head; dA7 = dX8 (.) C8
+    bwd_layer<8, 8, 0, 32, EPI_SIN, true>(c, slot, 0, ds, sel_x, acc, X, acts(16), grads(7), 256, p, valid);
+#pragma unroll 1
+    for (int l = 7; l >= 2; --l)                                                                // L7^T .. L2^T: dA_{l-1} = dX_l (.) C_l
+        bwd_layer<8, 8, 0, 32, EPI_SIN, false>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(8 + 512 * (l - 1) + 256) * P,
+                                               a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid);
+    bwd_layer<8, 8, 0, 0, EPI_SIN, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(0), 256, p, valid);   // L1^T: dA0 = dX1 (.) C1
 }
 
 // =========================================================================================
@@ -550,22 +583,47 @@ __global__ __launch_bounds__(256) void thin_grad_kernel(const float* __restrict_
                                                         const float* __restrict__ H, int ldh, int F, int64_t P,
                                                         int slab_pts, float* __restrict__ partial,
                                                         float* __restrict__ bias_partial) {
-    const int f = threadIdx.x;
+    // wave w takes points p0 + w, p0 + w + 4, ...; lane l the features 4l..4l+3 (float4 rows, 4 points in flight);
+    // the four waves' sums are added in wave order at the end, so the result does not depend on timing
+    __shared__ float red[4][4][256];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
     const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-    for (int64_t p = p0; p < p1; ++p) {
+    const bool live = 4 * lane < F;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    const auto row = [&](int64_t p) {
+        return live ? *reinterpret_cast<const f32x4*>(H + p * ldh + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    const auto fma_row = [&](int64_t p, const f32x4& hv) {
         const float* sp = S + p * lds_ + c0;
         const float s0 = sp[0], s1 = nc > 1 ? sp[1] : 0.f, s2 = nc > 2 ? sp[2] : 0.f;
-        const float hv = f < F ? H[p * ldh + f] : 0.f;
-        a0 = fmaf(s0, hv, a0); a1 = fmaf(s1, hv, a1); a2 = fmaf(s2, hv, a2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a0[q] = fmaf(s0, hv[q], a0[q]); a1[q] = fmaf(s1, hv[q], a1[q]); a2[q] = fmaf(s2, hv[q], a2[q]);
+        }
         b0 += s0; b1 += s1; b2 += s2;
+    };
+    int64_t p = p0 + w;
+    for (; p + 12 < p1; p += 16) {
+        const f32x4 h0 = row(p), h1 = row(p + 4), h2 = row(p + 8), h3 = row(p + 12);
+        fma_row(p, h0); fma_row(p + 4, h1); fma_row(p + 8, h2); fma_row(p + 12, h3);
     }
+    for (; p < p1; p += 4) fma_row(p, row(p));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        red[w][0][4 * lane + q] = a0[q]; red[w][1][4 * lane + q] = a1[q]; red[w][2][4 * lane + q] = a2[q];
+    }
+    if (lane == 0) { red[w][3][0] = b0; red[w][3][1] = b1; red[w][3][2] = b2; }
+    __syncthreads();
+    const int f = threadIdx.x;
     float* out = partial + (int64_t)blockIdx.x * 4 * 256;
-    out[0 * 256 + f] = a0; out[1 * 256 + f] = a1; out[2 * 256 + f] = a2; out[3 * 256 + f] = 0.f;
-    if (f == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c * 256 + f] = ((red[0][c][f] + red[1][c][f]) + red[2][c][f]) + red[3][c][f];
+    out[3 * 256 + f] = 0.f;
+    if (f < 4) {
         float* bo = bias_partial + (int64_t)blockIdx.x * 4;
-        bo[0] = b0; bo[1] = b1; bo[2] = b2; bo[3] = 0.f;
+        bo[f] = f < 3 ? ((red[0][3][f] + red[1][3][f]) + red[2][3][f]) + red[3][3][f] : 0.f;
     }
 }
 
@@ -683,12 +741,26 @@ static int run_head(const float* dpre, int c0, int nc, const float* H, int ldh, 
 // bias gradient of a layer with no GEMM job (K = 3 inputs): column sums of dA over the points
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dA, int lda, int F, int64_t P,
                                                      int slab_pts, float* __restrict__ partial) {
-    const int f = threadIdx.x;
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
     const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
-    float s = 0.f;
-    if (f < F) for (int64_t p = p0; p < p1; ++p) s += dA[p * lda + f];
-    partial[(int64_t)blockIdx.x * 256 + f] = s;
+    const bool live = 4 * lane < F;
+    const auto row = [&](int64_t p) {
+        return live ? *reinterpret_cast<const f32x4*>(dA + p * lda + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int64_t p = p0 + w;
+    for (; p + 12 < p1; p += 16) {
+        const f32x4 h0 = row(p), h1 = row(p + 4), h2 = row(p + 8), h3 = row(p + 12);
+        s = ((s + h0) + h1) + h2 + h3;
+    }
+    for (; p < p1; p += 4) s = s + row(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[w][4 * lane + q] = s[q];
+    __syncthreads();
+    const int f = threadIdx.x;
+    partial[(int64_t)blockIdx.x * 256 + f] = ((red[0][f] + red[1][f]) + red[2][f]) + red[3][f];
 }
 
 static int run_colsum(const float* dA, int lda, int F, int64_t P, float* partial, float* gb, hipStream_t stream) {

@@ -1,0 +1,28 @@
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "msra-practice-project_amd")]
+import numpy as np, torch
+from mirender import fields, ops, render_core
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+def run(name, cls, n, nc, nf, near, far, film=None):
+    cm = cls().to(dev)
+    fm = cm if film is not None else cls().to(dev)
+    rays = torch.randn(n, 2, 3, device=dev); rays[:, 0] = torch.tensor([0., 0., 1.0 if film is not None else 4.], device=dev); rays[:, 1, 2] = -1
+    tgt = torch.rand(n, 3, device=dev)
+    params = list(cm.parameters()) + ([] if fm is cm else list(fm.parameters()))
+    def step():
+        out = render_core.render_rays(rays, near, far, cm, fm, nc, nf, film=film)
+        loss = ((out[3] - tgt) ** 2).mean() + ((out[0] - tgt) ** 2).mean()
+        for p in params: p.grad = None
+        if film is not None: film.grad = None
+        loss.backward()
+    for _ in range(2): step()
+    torch.cuda.synchronize(); t = time.time(); k = 4
+    for _ in range(k): step()
+    torch.cuda.synchronize(); dt = (time.time() - t) / k
+    print(f"{name} train n={n} {nc}+{nf}: {dt*1e3:.2f} ms/step  {n/dt:.0f} rays/s", flush=True)
+run("nerf", fields.NeRF, 8192, 64, 128, 2.0, 6.0)
+run("siren", fields.SirenNeRF, 8192, 64, 128, 2.0, 6.0)
+film = (torch.rand((8, 9, 512), device=dev) + 0.5).requires_grad_(True)
+run("film", fields.FilmSirenNeRF, 8 * 16384, 12, 24, 0.5, 1.5, film=film)
