@@ -165,6 +165,26 @@ int mi_field_backward(int kind, const float* packed_bwd, const float* film, cons
                       float* partial_ws, float* film_partial_ws, float* const* grad_params, int n_params,
                       float* grad_film, void* stream);
 
+/* ---- evaluation stages (frame metrics, density grids) --------------------- */
+
+/* Frame metrics of nerf/test_nerf.py:102-105: mean squared error (psnr = -10 log10 mse) and
+ * pytorch_ssim.ssim (nerf/pytorch_ssim/__init__.py:12-37, 66-73: gaussian window, zero padding, groups =
+ * channels, C1 = 0.01^2, C2 = 0.03^2) of two image batches [images][channels][height][width] (planar, as the
+ * reference passes them: NCHW).  window: HOST array of window_size (odd, <= 31) normalised 1-D gaussian taps
+ * (the reference's gaussian(window_size, 1.5), __init__.py:7-10); the 2-D window is its outer product.
+ *   out [images][2] = {mse, mean ssim} per image (size_average=True is their mean: images have equal size)
+ *   workspace [mi_image_metrics_workspace_floats(...)] */
+int64_t mi_image_metrics_workspace_floats(int images, int channels, int height, int width);
+int mi_image_metrics(const float* img1, const float* img2, int images, int channels, int height, int width,
+                     const float* window, int window_size, float* workspace, float* out, void* stream);
+
+/* Query points of create_mesh's voxel grid (pi_GAN/utils.py:57-75): for overall index i in [head, head+count):
+ * (x,y,z) = (i/N/N%N, i/N%N, i%N) * voxel_size + (origin[2], origin[1], origin[0]) - the reference's axis
+ * order - and a zero view direction.  voxel_origin: HOST array of 3 floats.  out points [count,6], ready for
+ * mi_field_eval_points. */
+int mi_grid_points(int n, const float* voxel_origin, float voxel_size, int64_t head, int64_t count, float* points,
+                   void* stream);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 
 /* HIP events owned by the library's HIP runtime (the one the kernels launch on), so a host

@@ -251,6 +251,31 @@ int mi_field_backward(int kind, const float* packed_bwd, const float* film, cons
 void mi_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
 #endif
 
+int64_t mi_image_metrics_workspace_floats(int images, int channels, int height, int width) {
+    if (images <= 0 || channels <= 0 || height <= 0 || width <= 0) return 0;
+    return image_metrics_workspace_floats(images, channels, height, width);
+}
+
+int mi_image_metrics(const float* img1, const float* img2, int images, int channels, int height, int width,
+                     const float* window, int window_size, float* workspace, float* out, void* stream) {
+    if (!img1 || !img2 || !window || !workspace || !out || images <= 0 || channels <= 0 || height <= 0 || width <= 0 ||
+        window_size < 1 || window_size > 31 || window_size % 2 == 0) {
+        set_error("mi_image_metrics: bad arguments (window must be odd and <= 31)");
+        return MI_EINVAL;
+    }
+    return launch_image_metrics(img1, img2, images, channels, height, width, window, window_size, workspace, out,
+                                (hipStream_t)stream);
+}
+
+int mi_grid_points(int n, const float* voxel_origin, float voxel_size, int64_t head, int64_t count, float* points,
+                   void* stream) {
+    if (n <= 0 || !voxel_origin || head < 0 || count < 0 || head + count > (int64_t)n * n * n || (count > 0 && !points)) {
+        set_error("mi_grid_points: bad arguments (need 0 <= head, head + count <= n^3)");
+        return MI_EINVAL;
+    }
+    return launch_grid_points(n, voxel_origin, voxel_size, head, count, points, (hipStream_t)stream);
+}
+
 void* mi_event_create(void) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }

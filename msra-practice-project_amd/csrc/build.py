@@ -21,6 +21,7 @@ SOURCES = {
     "field_mlp_bwd.hip": [],
     # un-fused mul/add like the torch / NumPy ops these kernels restate
     "render_stages.hip": ["-ffp-contract=off"],
+    "eval_stages.hip": ["-ffp-contract=off"],
     "api.hip": [],
 }
 HEADERS = ["field_layout.h", "mi_common.h", "mi_math.h", "field_mlp_device.h", os.path.join("..", "..", "include", "mi_render.h")]

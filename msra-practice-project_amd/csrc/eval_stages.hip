@@ -1,0 +1,161 @@
+// eval_stages.hip - evaluation-side consumers/producers of the render path (gfx950), SURVEY.md 8(f) ranks 3-4.
+//
+//   image_metrics_kernel   mse + pytorch_ssim.ssim        reference nerf/test_nerf.py:102-105,
+//                                                          nerf/pytorch_ssim/__init__.py:12-37
+//   grid_points_kernel     voxel-grid query points        pi_GAN/utils.py:57-75 (create_mesh)
+//
+// Both are HBM-bound streaming kernels next to a frame's 1.9e14 FLOP; they exist so a rendered frame is scored,
+// and a density grid is sampled, without leaving the device.  Compiled with -ffp-contract=off (un-fused mul/add
+// like the torch ops they restate).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_common.h"
+
+namespace mi {
+
+constexpr int kMaxWindow = 31;
+struct Window { float g[kMaxWindow + 1]; int size; };
+
+constexpr int kTile = 32;                       // output pixels per workgroup side
+
+// One workgroup = one 32x32 output tile of one (image, channel) plane.
+// Stage 1: the (32+2r)^2 halo of both images into LDS (zero outside the plane = F.conv2d's zero padding).
+// Stage 2: horizontal 1-D gaussian of the five planes a, b, a*a, b*b, a*b  -> hbuf[5][32+2r][32].
+// Stage 3: vertical 1-D gaussian, the SSIM map value, block sums of ssim and (a-b)^2 -> partial[block][2].
+// The reference convolves with the 2-D window g g^T (121 taps); the separable form differs from it by fp32
+// rounding only (measured against the oracle in tests/test_gpu_metrics.py).
+__global__ __launch_bounds__(256) void image_metrics_kernel(const float* __restrict__ img1,
+                                                            const float* __restrict__ img2, int H, int W, Window win,
+                                                            float* __restrict__ partial) {
+    extern __shared__ float lds[];
+    const int r = win.size / 2, span = kTile + 2 * r;
+    float* a = lds;                         // [span][span]
+    float* b = a + span * span;             // [span][span]
+    float* hb = b + span * span;            // [5][span][kTile]
+    __shared__ float red[2][4];
+    const int64_t plane = blockIdx.z;
+    const float* p1 = img1 + plane * H * W;
+    const float* p2 = img2 + plane * H * W;
+    const int x0 = blockIdx.x * kTile - r, y0 = blockIdx.y * kTile - r;
+    for (int i = threadIdx.x; i < span * span; i += 256) {
+        const int y = y0 + i / span, x = x0 + i % span;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        a[i] = in ? p1[(int64_t)y * W + x] : 0.f;
+        b[i] = in ? p2[(int64_t)y * W + x] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < span * kTile; i += 256) {
+        const int row = i / kTile, col = i % kTile;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+        for (int t = 0; t < win.size; ++t) {
+            const float g = win.g[t], va = a[row * span + col + t], vb = b[row * span + col + t];
+            s0 += g * va; s1 += g * vb; s2 += g * (va * va); s3 += g * (vb * vb); s4 += g * (va * vb);
+        }
+        hb[(0 * span + row) * kTile + col] = s0; hb[(1 * span + row) * kTile + col] = s1;
+        hb[(2 * span + row) * kTile + col] = s2; hb[(3 * span + row) * kTile + col] = s3;
+        hb[(4 * span + row) * kTile + col] = s4;
+    }
+    __syncthreads();
+    float ssim_sum = 0.f, se_sum = 0.f;
+    for (int i = threadIdx.x; i < kTile * kTile; i += 256) {
+        const int row = i / kTile, col = i % kTile;
+        const int y = blockIdx.y * kTile + row, x = blockIdx.x * kTile + col;
+        if (y >= H || x >= W) continue;
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        for (int t = 0; t < win.size; ++t) {
+            const float g = win.g[t];
+            mu1 += g * hb[(0 * span + row + t) * kTile + col]; mu2 += g * hb[(1 * span + row + t) * kTile + col];
+            e11 += g * hb[(2 * span + row + t) * kTile + col]; e22 += g * hb[(3 * span + row + t) * kTile + col];
+            e12 += g * hb[(4 * span + row + t) * kTile + col];
+        }
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu1_mu2;
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        ssim_sum += ((2.f * mu1_mu2 + C1) * (2.f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+        const float d = a[(row + r) * span + col + r] - b[(row + r) * span + col + r];
+        se_sum += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        ssim_sum += __shfl_xor(ssim_sum, off);
+        se_sum += __shfl_xor(se_sum, off);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ssim_sum; red[1][threadIdx.x >> 6] = se_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t blk = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partial[blk * 2 + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        partial[blk * 2 + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    }
+}
+
+// out[n] = {mean squared error, mean ssim} of image n: fixed-order fp64 sum of its blocks' partials.
+__global__ __launch_bounds__(256) void image_metrics_reduce_kernel(const float* __restrict__ partial,
+                                                                   int64_t blocks_per_image, double inv_count,
+                                                                   float* __restrict__ out) {
+    __shared__ double red[2][256];
+    const float* src = partial + (int64_t)blockIdx.x * blocks_per_image * 2;
+    double s = 0.0, e = 0.0;
+    for (int64_t i = threadIdx.x; i < blocks_per_image; i += 256) { s += src[i * 2]; e += src[i * 2 + 1]; }
+    red[0][threadIdx.x] = s; red[1][threadIdx.x] = e;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + w];
+            red[1][threadIdx.x] += red[1][threadIdx.x + w];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[blockIdx.x * 2 + 0] = (float)(red[1][0] * inv_count);
+        out[blockIdx.x * 2 + 1] = (float)(red[0][0] * inv_count);
+    }
+}
+
+int64_t image_metrics_workspace_floats(int images, int channels, int H, int W) {
+    const int64_t bx = (W + kTile - 1) / kTile, by = (H + kTile - 1) / kTile;
+    return (int64_t)images * channels * bx * by * 2;
+}
+
+int launch_image_metrics(const float* img1, const float* img2, int images, int channels, int H, int W,
+                         const float* window, int window_size, float* workspace, float* out, hipStream_t stream) {
+    Window win{};
+    win.size = window_size;
+    for (int i = 0; i < window_size; ++i) win.g[i] = window[i];
+    const int span = kTile + 2 * (window_size / 2);
+    const size_t lds = (size_t)(2 * span * span + 5 * span * kTile) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("image_metrics: window %d needs %zu B of LDS", window_size, lds); return -1; }
+    const unsigned bx = (W + kTile - 1) / kTile, by = (H + kTile - 1) / kTile;
+    const int64_t planes = (int64_t)images * channels;
+    if (planes > 65535) { set_error("image_metrics: too many planes (%lld)", (long long)planes); return -1; }
+    hipLaunchKernelGGL(image_metrics_kernel, dim3(bx, by, (unsigned)planes), dim3(256), lds, stream, img1, img2, H, W, win,
+                       workspace);
+    hipLaunchKernelGGL(image_metrics_reduce_kernel, dim3(images), dim3(256), 0, stream, workspace,
+                       (int64_t)channels * bx * by, 1.0 / ((double)channels * H * W), out);
+    return check_launch("image_metrics");
+}
+
+// create_mesh's sample grid (pi_GAN/utils.py:57-75): overall index i -> (i / N^2 % N, i / N % N, i % N) scaled by
+// voxel_size and shifted by voxel_origin[2], [1], [0] respectively (the reference's axis order), view dir = 0.
+__global__ void grid_points_kernel(int N, float o0, float o1, float o2, float voxel_size, int64_t head, int64_t count,
+                                   float* __restrict__ pts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int64_t idx = head + i;
+    const float fx = (float)(idx / N / N % N), fy = (float)(idx / N % N), fz = (float)(idx % N);
+    float* p = pts + i * 6;
+    p[0] = fx * voxel_size + o2;
+    p[1] = fy * voxel_size + o1;
+    p[2] = fz * voxel_size + o0;
+    p[3] = 0.f; p[4] = 0.f; p[5] = 0.f;
+}
+
+int launch_grid_points(int N, const float* origin, float voxel_size, int64_t head, int64_t count, float* pts,
+                       hipStream_t stream) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL(grid_points_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, N, origin[0],
+                       origin[1], origin[2], voxel_size, head, count, pts);
+    return check_launch("grid_points");
+}
+
+}  // namespace mi

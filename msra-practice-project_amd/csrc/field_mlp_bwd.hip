@@ -284,7 +284,6 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
     const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
-    const auto zero = [&](f32x16 (&x)[8]) { init_zero<8>(x); };
 
     __syncthreads();
     {   // dX_d = W_rgb^T d_pre_rgb (128 features)

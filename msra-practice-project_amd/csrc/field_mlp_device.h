@@ -147,15 +147,15 @@ __device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f3
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (first_mm && m + 1 < MB) pre(ic<m + 1>{}, qc);
                     if constexpr (last_mm) {
-                        if constexpr (q >= 1 && m >= 1) post(ic<m - 1>{}, ic<q - 1>{});
-                        if constexpr (q == 0 && m >= 2) post(ic<m - 2>{}, ic<3>{});
+                        if constexpr (q >= 1 && m >= 1) post(ic<(m >= 1 ? m - 1 : 0)>{}, ic<(q >= 1 ? q - 1 : 0)>{});
+                        if constexpr (q == 0 && m >= 2) post(ic<(m >= 2 ? m - 2 : 0)>{}, ic<3>{});
                     }
                     if constexpr (rg == 0 && q == 3) slot(ic<m>{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
             if constexpr (last_mm) {
-                if constexpr (MB >= 2) post(ic<MB - 2>{}, ic<3>{});
+                if constexpr (MB >= 2) post(ic<(MB >= 2 ? MB - 2 : 0)>{}, ic<3>{});
                 static_for<4>([&](auto pc) { post(ic<MB - 1>{}, pc); });
             }
         } else {

@@ -67,6 +67,11 @@ int launch_composite(int64_t n, int S, const float* raw, const float* z, const f
                      float* acc, float* weights, hipStream_t stream);
 int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,
                          const float* g_depth, const float* g_acc, float* g_raw, hipStream_t stream);
+int64_t image_metrics_workspace_floats(int images, int channels, int H, int W);
+int launch_image_metrics(const float* img1, const float* img2, int images, int channels, int H, int W,
+                         const float* window, int window_size, float* workspace, float* out, hipStream_t stream);
+int launch_grid_points(int N, const float* origin, float voxel_size, int64_t head, int64_t count, float* pts,
+                       hipStream_t stream);
 int launch_sample_pdf(int64_t n, int nb, int ns, const float* bins, const float* weights, const float* u_lin, float* out,
                       hipStream_t stream);
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,

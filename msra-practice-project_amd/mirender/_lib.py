@@ -38,6 +38,9 @@ SIGNATURES = {
     "mi_composite": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sample_fine": (_int, [_i64, _f32, _f32, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sample_pdf": (_int, [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "mi_image_metrics_workspace_floats": (_i64, [_int, _int, _int, _int]),
+    "mi_image_metrics": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
+    "mi_grid_points": (_int, [_int, _vp, _f32, _i64, _i64, _vp, _vp]),
     "mi_render_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
                               _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

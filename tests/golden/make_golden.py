@@ -15,6 +15,7 @@ Fixture families:
   F5 render_*      render_rays with all intermediates
   F6 pigan_grad    pi_GAN image + grads wrt FiLM table and field weights
   F7 nerf_grad     nerf training loss grads for one ray batch
+  F8 metrics       pytorch_ssim.ssim / mse / psnr of synthetic frame pairs (nerf/test_nerf.py:102-104)
 """
 import contextlib
 import os
@@ -118,7 +119,50 @@ def grad_summary(named_grads):
     return out
 
 
+def synth_frames(n, c, h, w, seed, noise):
+    """Smooth 'rendered' frames in [0,1] and a noisy copy (a stand-in for a target photograph)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32), np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
+    a = np.empty((n, c, h, w), np.float32)
+    for i in range(n):
+        for k in range(c):
+            fx, fy, ph = rng.uniform(1, 9), rng.uniform(1, 9), rng.uniform(0, 6.28)
+            a[i, k] = 0.5 + 0.35 * np.sin(fx * xx * 6.28 + ph) * np.cos(fy * yy * 6.28) + 0.1 * (xx > 0.5)
+    b = np.clip(a + noise * rng.standard_normal(a.shape).astype(np.float32), 0, 1).astype(np.float32)
+    return torch.from_numpy(np.clip(a, 0, 1)), torch.from_numpy(b)
+
+
+def make_metrics():
+    """F8: the reference's own pytorch_ssim package on CPU (nerf/pytorch_ssim/__init__.py), plus the mse / psnr
+    expressions of nerf/test_nerf.py:102-103."""
+    sys.path.insert(0, os.path.join(REF, "nerf"))
+    import pytorch_ssim  # noqa
+    sys.path.pop(0)
+    out = {}
+    cases = [("ragged", 2, 3, 37, 53, 0.05), ("frame", 1, 3, 100, 100, 0.02), ("tiny", 1, 1, 5, 7, 0.1),
+             ("wide", 3, 3, 16, 130, 0.2)]
+    for name, n, c, h, w, noise in cases:
+        a, b = synth_frames(n, c, h, w, seed=len(name) * 17 + h, noise=noise)
+        out[f"{name}.img1"], out[f"{name}.img2"] = a.numpy(), b.numpy()
+        out[f"{name}.ssim"] = pytorch_ssim.ssim(a, b).numpy()
+        out[f"{name}.ssim_per_image"] = pytorch_ssim.ssim(a, b, size_average=False).numpy()
+        out[f"{name}.ssim_w7"] = pytorch_ssim.ssim(a, b, window_size=7).numpy()
+        out[f"{name}.ssim_module"] = pytorch_ssim.SSIM()(a, b).numpy()
+        mse = torch.mean((a - b) ** 2)
+        out[f"{name}.mse"] = mse.numpy()
+        out[f"{name}.psnr"] = np.float64(-10 * torch.log10(mse).item())
+    a, _ = synth_frames(1, 3, 40, 40, seed=5, noise=0.0)
+    out["same.img1"] = a.numpy()
+    out["same.ssim"] = pytorch_ssim.ssim(a, a.clone()).numpy()
+    flat = torch.full((1, 3, 33, 33), 0.25)
+    out["flat.ssim_vs_half"] = pytorch_ssim.ssim(flat, torch.full((1, 3, 33, 33), 0.5)).numpy()
+    save("metrics_f8", **out)
+
+
 def main():
+    if "--only-metrics" in sys.argv:
+        make_metrics()
+        return
     torch.set_num_threads(8)
     nr, nm, nd, pr, pm = load_reference()
 
@@ -288,6 +332,7 @@ def main():
     save("nerf_grad_f7", rays=rays, t_rand=tr, target=tgt, near=2.0, far=6.0, n_coarse=nc, n_fine=nf,
          loss=loss, rgb_c=rgb_c, acc_c=acc_c, rgb_f=rgb_f, acc_f=acc_f,
          digest_c=np.array(synth.digest(sd_c)), digest_f=np.array(synth.digest(sd_f)), **grad_summary(named))
+    make_metrics()
     print("specs:", {k: len(v) for k, v in SPECS.items()})
 
 

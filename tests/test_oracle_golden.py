@@ -156,3 +156,45 @@ def test_f7_nerf_loss_grads(golden):
     loss.backward()
     _check_grads(g, "coarse.", list(sd_c.items()))
     _check_grads(g, "fine.", list(sd_f.items()))
+
+
+# ---- F8: frame metrics (nerf/test_nerf.py:102-104, nerf/pytorch_ssim) ---------------------------------
+METRIC_CASES = ["ragged", "frame", "tiny", "wide"]
+
+
+@pytest.mark.parametrize("name", METRIC_CASES)
+def test_f8_metrics(golden, name):
+    from oracle import metrics as M
+    g = golden("metrics_f8")
+    a, b = torch.from_numpy(g[f"{name}.img1"]), torch.from_numpy(g[f"{name}.img2"])
+    assert abs(float(M.ssim(a, b)) - float(g[f"{name}.ssim"])) <= 1e-6
+    assert np.abs(M.ssim(a, b, size_average=False).numpy() - g[f"{name}.ssim_per_image"]).max() <= 1e-6
+    assert abs(float(M.ssim(a, b, window_size=7)) - float(g[f"{name}.ssim_w7"])) <= 1e-6
+    assert float(g[f"{name}.ssim_module"]) == float(g[f"{name}.ssim"])
+    assert abs(float(M.mse(a, b)) - float(g[f"{name}.mse"])) <= 1e-9
+    assert abs(float(M.psnr(a, b)) - float(g[f"{name}.psnr"])) <= 1e-5
+
+
+def test_f8_metrics_degenerate(golden):
+    from oracle import metrics as M
+    g = golden("metrics_f8")
+    a = torch.from_numpy(g["same.img1"])
+    assert abs(float(M.ssim(a, a.clone())) - float(g["same.ssim"])) <= 1e-6
+    flat = torch.full((1, 3, 33, 33), 0.25)
+    assert abs(float(M.ssim(flat, torch.full((1, 3, 33, 33), 0.5))) - float(g["flat.ssim_vs_half"])) <= 1e-6
+
+
+def test_grid_samples_restatement():
+    """create_mesh's sample table (pi_GAN/utils.py:57-71): axis order and fp32 arithmetic of the restatement."""
+    from oracle import grid as G
+    n = 5
+    pts = G.grid_samples(n).numpy()
+    vs = np.float32(0.2 / (n - 1))
+    idx = np.arange(n ** 3)
+    exp = np.stack([(idx // n // n % n).astype(np.float32) * vs + np.float32(-0.1),
+                    (idx // n % n).astype(np.float32) * vs + np.float32(-0.1),
+                    (idx % n).astype(np.float32) * vs + np.float32(-0.1)], -1)
+    assert pts.dtype == np.float32 and np.array_equal(pts, exp)
+    # non-cubic origin: x takes origin[2], z takes origin[0] (the reference's order)
+    pts = G.grid_samples(3, voxel_origin=(1.0, 2.0, 3.0), voxel_size=0.5).numpy()
+    assert pts[0].tolist() == [3.0, 2.0, 1.0] and pts[-1].tolist() == [4.0, 3.0, 2.0]

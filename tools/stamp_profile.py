@@ -37,21 +37,20 @@ for rep in range(2):
     lib.mi_field_eval_points(0, vp(packed.data_ptr()), None, vp(x.data_ptr()), 1, M, vp(out.data_ptr()), None)
     torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.int64)
-names = {0: "entry", 1: "prologue (load point, PE)", 2: "L0 mfma (2 K-blocks)", 3: "L0 act"}
-for l in range(1, 5):
-    names[2 + 2 * l] = f"L{l} mfma (8)"
-    names[3 + 2 * l] = f"L{l} act"
-names.update({12: "L5 mfma (10)", 13: "L5 act", 14: "L6 mfma (8)", 15: "L6 act", 16: "L7 mfma (8)", 17: "L7 act + sigma head",
-              18: "dir0 mfma (8)", 19: "dir0 copy", 20: "dir1 mfma (9, MB=4)", 21: "dir1 act + rgb head + store"})
-ideal = {2: 2 * 8192, 12: 10 * 8192, 20: 9 * 4096}
-for k in (4, 6, 8, 10, 14, 16, 18):
+# stamps present in the kernel (activation and bias preload are sliced into the layer's MFMA phases)
+marks = [0, 1, 3, 5, 7, 9, 11, 13, 15, 17, 19, 20, 21]
+names = {1: "prologue (load point, PE)", 3: "L0 (2 K-blocks)", 5: "L1 (8)", 7: "L2 (8)", 9: "L3 (8)", 11: "L4 (8)",
+         13: "L5 (10)", 15: "L6 (8)", 17: "L7 (8) + sigma head", 19: "dir0 (8, linear)", 20: "dir1 (9, MB=4)",
+         21: "rgb head + store"}
+ideal = {3: 2 * 8192, 13: 10 * 8192, 20: 9 * 4096}
+for k in (5, 7, 9, 11, 15, 17, 19):
     ideal[k] = 8 * 8192
 body = s[512:]                                   # skip the first wave of workgroups (cold caches)
 total = np.median(body[:, 21] - body[:, 0])
 print(f"tile total (median) {total:.0f} cycles (memtime ticks); ideal MFMA 593920")
 acc_mfma = acc_ideal = 0
-for i in range(1, 22):
-    d = np.median(body[:, i] - body[:, i - 1])
+for prev, i in zip(marks[:-1], marks[1:]):
+    d = np.median(body[:, i] - body[:, prev])
     extra = f"  ideal {ideal[i]}  overhead {d - ideal[i]:.0f}" if i in ideal else ""
     if i in ideal:
         acc_mfma += d; acc_ideal += ideal[i]
