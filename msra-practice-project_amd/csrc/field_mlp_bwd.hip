@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = 4;    // point pairs per step; the next step's rows are loaded before this step's MFMAs
+    constexpr int U = 8;    // point pairs per step; the next step's rows are loaded before this step's MFMAs (8192 MFMA cycles of lead)
     const int64_t step = 2 * KS * U;
     f32x4 av[U], an[U];
     bvec bv[U], bn[U];
@@ -673,7 +673,7 @@ int64_t film_partial_floats(int64_t n_groups, int64_t points_per_group) {
 }
 
 static int slab_points(int64_t P) {
-    int64_t s = (P + 511) / 512;           // aim at ~512 workgroups (2 per CU)
+    int64_t s = (P + 255) / 256;           // aim at one workgroup per CU: fewer partial tiles to write and reduce
     s = (s + 31) / 32 * 32;
     if (s < 256) s = 256;
     return (int)s;
