@@ -147,9 +147,16 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
         // layers_pos[1..4]
 #pragma unroll 1
         for (int l = 1; l <= 4; ++l) {
+#ifdef MI_PROFILE_STAMPS
+            if (l == 2 && a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;   // rows of layers_pos[2]: 32..64
+#endif
             fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
                                                                  rows(64 + 256 * l, 256));   // H2..H5
             slot ^= 1;
+            MI_ROW_STAMP(c);
+#ifdef MI_PROFILE_STAMPS
+            c.rowst = nullptr;
+#endif
             MI_STAMP(a, 3 + 2 * l);
         }
         // layers_pos[5]: [PE(60) | h(256)] -> 256

@@ -45,16 +45,15 @@ struct Ctx {
     int voff;                       // per-lane byte offset inside a round of 4 pieces: wave * 1024 + lane * 16
     int lane, wave, h;
 #ifdef MI_PROFILE_STAMPS
-    unsigned long long* stamps;   // diagnostic build: this block's stamp row
-    int stage_id;
+    unsigned long long* rowst;    // diagnostic build: next per-row stamp slot of this block (null = off)
 #endif
 };
 
 #ifdef MI_PROFILE_STAMPS
-// stamps 22..27 bracket the barrier of one mid-kernel K-block stage (stage 40)
-#define MI_CSTAMP(c, i) do { if ((c).stage_id == 40 && threadIdx.x == 0 && (c).stamps) (c).stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// diagnostic build: one s_memtime per row of MFMAs (4 per K block) while c.rowst is set
+#define MI_ROW_STAMP(c) do { if ((c).rowst) { if (threadIdx.x == 0) *(c).rowst = __builtin_amdgcn_s_memtime(); ++(c).rowst; } } while (0)
 #else
-#define MI_CSTAMP(c, i) do { } while (0)
+#define MI_ROW_STAMP(c) do { } while (0)
 #endif
 
 // LDS-DMA of 1 KiB pieces (buffer_load_dwordx4 ... lds): per piece one SALU add for M0 and one VMEM issue -
@@ -127,11 +126,12 @@ struct NoHook {
 template <int I> using ic = std::integral_constant<int, I>;
 
 template <int MB, int ORDER, class Slot, class Pre, class Post>
-__device__ __forceinline__ void mma_chunk(const float* chunk, int lane, const f32x16& b, f32x16 (&acc)[8], Slot slot,
+__device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x16& b, f32x16 (&acc)[8], Slot slot,
                                           Pre pre, Post post) {
-    const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + lane;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + c.lane;
     static_for<4>([&](auto rgc) {
         constexpr int rg = decltype(rgc)::value;
+        MI_ROW_STAMP(c);
         f32x4 a[MB];
 #pragma unroll
         for (int m = 0; m < MB; ++m) a[m] = a4[(rg * MB + m) * 64];
@@ -293,12 +293,12 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
         __syncthreads();
         if constexpr (i == 0 && !HOOKS) init(acc);
         const float* buf = c.smem + kLdsChunk0 + c.buf * kLdsChunk;
-        mma_chunk<MB, order0>(buf, c.lane, bsel(ic<kb0>{}), acc, [&](auto sc) {
+        mma_chunk<MB, order0>(c, buf, bsel(ic<kb0>{}), acc, [&](auto sc) {
             constexpr int S = decltype(sc)::value;
             if constexpr (next_blocks > 0) issue_stage_slot<0, next_blocks * MB * 4, false, MB, S>(c, 0, c.buf ^ 1, 0);
             else issue_stage_slot<NEXT_AUX, 2 * NEXT_BLOCK, FILM, MB, S>(c, aux_slot ^ 1, c.buf ^ 1, next_film_layer);
         }, pre, post);
-        if constexpr (two) mma_chunk<MB, order1>(buf + MB * 1024, c.lane, bsel(ic<kb0 + 1>{}), acc, NoHook{}, pre, post);
+        if constexpr (two) mma_chunk<MB, order1>(c, buf + MB * 1024, bsel(ic<kb0 + 1>{}), acc, NoHook{}, pre, post);
         c.buf ^= 1;
     };
     static_for<(KB + 1) / 2>(stage);
@@ -505,8 +505,7 @@ __device__ __forceinline__ Ctx make_ctx_raw(float* smem, const float* packed, co
     c.buf = 0;
     c.voff = c.wave * 1024 + c.lane * 16;
 #ifdef MI_PROFILE_STAMPS
-    c.stamps = nullptr;
-    c.stage_id = 0;
+    c.rowst = nullptr;
 #endif
     return c;
 }

@@ -36,13 +36,13 @@ struct MlpArgs {
     int mode;
     float* save;            // training: saved layer inputs, region r = save + act_offset(r) * save_points
     int64_t save_points;    // points in this launch (row count of every saved region)
-    unsigned long long* stamps;   // diagnostic build (-DMI_PROFILE_STAMPS) only: [block][32] s_memtime values
+    unsigned long long* stamps;   // diagnostic build (-DMI_PROFILE_STAMPS) only: [block][128] s_memtime values
 };
 
 // In-kernel cycle stamps for the diagnostic build (csrc/build.py --profile -> gpurun_tools/libmirender_prof.so);
 // the product build compiles them out.
 #ifdef MI_PROFILE_STAMPS
-#define MI_STAMP(a, i) do { if (threadIdx.x == 0 && (a).stamps) (a).stamps[(int64_t)blockIdx.x * 32 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MI_STAMP(a, i) do { if (threadIdx.x == 0 && (a).stamps) (a).stamps[(int64_t)blockIdx.x * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define MI_STAMP(a, i) do { } while (0)
 #endif

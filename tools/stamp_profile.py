@@ -31,7 +31,7 @@ lib.mi_field_pack(0, arr, len(params), vp(packed.data_ptr()), None)
 M = 128 * 256 * 24                      # 24 tiles per CU
 x = torch.rand((M, 6), device=dev) * 2 - 1
 out = torch.empty((M, 4), device=dev)
-stamps = torch.zeros((M // 128, 32), dtype=torch.int64, device=dev)
+stamps = torch.zeros((M // 128, 128), dtype=torch.int64, device=dev)
 for rep in range(2):
     lib.mi_debug_set_stamps(vp(stamps.data_ptr()))
     lib.mi_field_eval_points(0, vp(packed.data_ptr()), None, vp(x.data_ptr()), 1, M, vp(out.data_ptr()), None)
@@ -58,3 +58,9 @@ for prev, i in zip(marks[:-1], marks[1:]):
 print(f"mfma phases {acc_mfma:.0f} vs ideal {acc_ideal} -> {100 * acc_ideal / acc_mfma:.1f} % ; non-mfma phases {total - acc_mfma:.0f} ({100 * (total - acc_mfma) / total:.1f} %)")
 gaps = np.median(s[768:, 0] - s[512:-256, 21])    # start of a tile vs end of the tile 256 workgroups earlier (same CU, roughly)
 print(f"approx. workgroup turnaround on a CU: {gaps:.0f}")
+# per-row stamps of layers_pos[2] (8 K blocks x 4 rows of 32 MFMAs = 2048 cycles each): 32..64
+rows = np.median(body[:, 33:65] - body[:, 32:64], axis=0)
+print("layers_pos[2] rows (cycles, ideal 2048 each; K block = 4 rows, stage = 2 K blocks):")
+for kb in range(8):
+    print(f"  K block {kb}: " + " ".join(f"{rows[4 * kb + r]:6.0f}" for r in range(4)) + ("   <- stage start (barrier, DMA slots)" if kb % 2 == 0 else ""))
+print(f"  sum {rows.sum():.0f} vs 65536")
