@@ -1,3 +1,4 @@
+"""RCCL smoke test on one GPU (1-rank process group): render_image_dist + allreduce_grads through the nccl backend."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "msra-practice-project_amd")]

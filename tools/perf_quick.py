@@ -1,5 +1,7 @@
+"""Micro-benchmark (GPU box): fused field MLP in points mode for every kind, as % of the fp32 MFMA peak, and one
+NeRF training step at 8192 rays.  Not a test; the judged numbers come from bench.py."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 sys.path[:0] = [ROOT, os.path.join(ROOT, "msra-practice-project_amd")]
 import numpy as np, torch
 from mirender import fields, ops, render_core

@@ -1,3 +1,5 @@
+"""Micro-benchmark (GPU box): training step times for NeRF / SirenNeRF (8192 rays, 64+128) and FilmSirenNeRF
+(8 images x 16384 rays, 12+24).  Not a test; the judged numbers come from bench.py --workload."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "msra-practice-project_amd")]
