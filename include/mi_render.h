@@ -155,15 +155,18 @@ int mi_field_eval_rays_train(int kind, const float* packed, const float* film, c
  * parameter gradients (and, for FiLM kinds, the gradient of the FiLM table).
  *   film            [n_groups,9,512] FiLM table of the forward (FiLM kinds) or NULL
  *   grad_params     HOST array of n_params device pointers (torch layouts, state-dict order), OVERWRITTEN
+ *   params          HOST array of the n_params parameter tensors themselves (FiLM kinds: the FiLM-table
+ *                   gradient is formed from the per-image weight-gradient sums, d gamma = <W, dW_image> +
+ *                   b . db_image); NULL for the other kinds
  *   grad_film       [n_groups,9,512] (FiLM kinds) or NULL, OVERWRITTEN
  *   grads_ws        [mi_field_train_grads_floats(kind) * points]
  *   partial_ws      [mi_field_bwd_partial_floats(points)]
- *   film_partial_ws [mi_field_film_partial_floats(n_groups, points_per_group)] (FiLM kinds) or NULL */
+ *   film_partial_ws [mi_field_film_partial_floats(n_groups, points_per_group)] FiLM scratch (FiLM kinds) or NULL */
 int64_t mi_field_film_partial_floats(int64_t n_groups, int64_t points_per_group);
 int mi_field_backward(int kind, const float* packed_bwd, const float* film, const float* acts, float* grads_ws,
                       const float* raw, const float* g_raw, int64_t n_groups, int64_t points_per_group,
-                      float* partial_ws, float* film_partial_ws, float* const* grad_params, int n_params,
-                      float* grad_film, void* stream);
+                      float* partial_ws, float* film_partial_ws, float* const* grad_params,
+                      const float* const* params, int n_params, float* grad_film, void* stream);
 
 /* ---- evaluation stages (frame metrics, density grids) --------------------- */
 

@@ -236,15 +236,18 @@ int64_t mi_field_film_partial_floats(int64_t n_groups, int64_t points_per_group)
 
 int mi_field_backward(int kind, const float* packed_bwd, const float* film, const float* acts, float* grads_ws,
                       const float* raw, const float* g_raw, int64_t n_groups, int64_t points_per_group,
-                      float* partial_ws, float* film_partial_ws, float* const* grad_params, int n_params,
-                      float* grad_film, void* stream) {
+                      float* partial_ws, float* film_partial_ws, float* const* grad_params,
+                      const float* const* params, int n_params, float* grad_film, void* stream) {
     if (bad_kind(kind)) return MI_EINVAL;
     if (!packed_bwd || !acts || !grads_ws || !raw || !g_raw || !partial_ws || !grad_params ||
         n_params != 2 * kNumLayers[kind]) { set_error("mi_field_backward: bad arguments"); return MI_EINVAL; }
-    for (int i = 0; i < n_params; ++i)
+    const bool film_kind = kind == 2 || kind == 3;
+    for (int i = 0; i < n_params; ++i) {
         if (!grad_params[i]) { set_error("gradient pointer %d is null", i); return MI_EINVAL; }
+        if (film_kind && (!params || !params[i])) { set_error("FiLM kinds need parameter pointer %d", i); return MI_EINVAL; }
+    }
     return launch_field_backward(kind, packed_bwd, acts, grads_ws, raw, g_raw, n_groups, points_per_group, film,
-                                 film_partial_ws, grad_film, partial_ws, grad_params, (hipStream_t)stream);
+                                 film_partial_ws, grad_film, partial_ws, grad_params, params, (hipStream_t)stream);
 }
 
 #ifdef MI_PROFILE_STAMPS

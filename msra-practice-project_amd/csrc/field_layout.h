@@ -231,13 +231,14 @@ constexpr RegionLayout siren_acts() {
     return {20, {8, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 128}};
 }
 constexpr RegionLayout siren_grads() { return nerf_grads(); }
-// FilmSirenNeRF acts: 0 xin(8) | FiLM layer l=0..8 (input, hidden 0..6, rgb hidden): 1+3l A_l (linear out),
-//                     2+3l X_l = sin(30 u), 3+3l C_l = 30 cos(30 u), u = gamma*A + beta.
-// grads: 0..8 dA_l (256) | 9 head pre-act grads (4)
+// FilmSirenNeRF acts: 0 xin(8) | FiLM layer l=0..8 (input, hidden 0..6, rgb hidden): 1+2l X_l = sin(30 u),
+//                     2+2l C_l = 30 cos(30 u), u = gamma*A + beta (the linear output A is not kept: the FiLM table
+//                     gradient comes out of the per-image dW sums, see launch_field_backward).
+// grads: 0..8 dL/du_l (256) | 9 head pre-act grads (4)
 constexpr RegionLayout film_acts() {
-    RegionLayout L{28, {}};
+    RegionLayout L{19, {}};
     L.width[0] = 8;
-    for (int i = 1; i < 28; ++i) L.width[i] = 256;
+    for (int i = 1; i < 19; ++i) L.width[i] = 256;
     return L;
 }
 constexpr RegionLayout film_grads() { return {10, {256, 256, 256, 256, 256, 256, 256, 256, 256, 4}}; }

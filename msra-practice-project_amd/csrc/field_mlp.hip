@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     constexpr RegionLayout RL = TINY ? tiny_acts() : nerf_acts();
     const int64_t SP = a.save_points;
     const auto rows = [&](int off_floats_per_point, int width) {
-        return SaveRows{nullptr, SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, nullptr, width, pt.p, pt.valid};
+        return SaveRows{SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, nullptr, width, pt.p, pt.valid};
     };
     if constexpr (SAVE) {
         f32x16 tmp[8];
@@ -232,11 +232,11 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     // sin layer l (1..8): X_l -> region 2l-1, C_l -> region 2l
     const auto sin_rows = [&](int l) {
         float* base = SAVE ? a.save + (int64_t)(8 + 512 * (l - 1)) * SP : nullptr;
-        return SaveRows{nullptr, base, SAVE ? base + 256 * SP : nullptr, 256, pt.p, pt.valid};
+        return SaveRows{base, SAVE ? base + 256 * SP : nullptr, 256, pt.p, pt.valid};
     };
     const auto sin_act = [&](int l) {
         if constexpr (SAVE)
-            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, nullptr, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
+            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
                                          a.save + (int64_t)(8 + 512 * (l - 1) + 256) * SP, 256, pt.p, pt.valid);
         else
             activate<8, ACT_SIN30>(acc, X, nullptr, c.h);
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     }
     slot ^= 1;
     fwd_layer<8, 8, false, 8, 16, false, ACT_LINEAR, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                           SaveRows{nullptr, SAVE ? region(17) : nullptr, nullptr, 256, pt.p, pt.valid});  // layers_dir[0] linear: G
+                                                           SaveRows{SAVE ? region(17) : nullptr, nullptr, 256, pt.p, pt.valid});  // layers_dir[0] linear: G
     slot ^= 1;
     fwd_layer<8, 4, true, 0, 0, false, ACT_SIN30, SAVE>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, nullptr,
-                                                        SaveRows{nullptr, SAVE ? region(18) : nullptr, SAVE ? region(19) : nullptr, 128, pt.p, pt.valid});  // layers_dir[1]: [h | dir]
+                                                        SaveRows{SAVE ? region(18) : nullptr, SAVE ? region(19) : nullptr, 128, pt.p, pt.valid});  // layers_dir[1]: [h | dir]
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 4, c.h) + aux[7 * kPiece + 0]);
     const float g = sigmoidf(head_dot<4>(X, aux, 5, c.h) + aux[7 * kPiece + 1]);
@@ -302,16 +302,15 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto film_row = [&](int s) { return smem + kLdsFilm0 + s * kFilmRow; };
     const int64_t SP = a.save_points;
-    // FiLM layer l (0..8): A_l -> region 1+3l, X_l -> 2+3l, C_l -> 3+3l (each 256 wide, after the 8-wide xin)
+    // FiLM layer l (0..8): X_l -> region 1+2l, C_l -> 2+2l (each 256 wide, after the 8-wide xin)
     const auto film_rows = [&](int l) {
-        float* base = SAVE ? a.save + (int64_t)(8 + 768 * l) * SP : nullptr;
-        return SaveRows{base, SAVE ? base + 256 * SP : nullptr, SAVE ? base + 512 * SP : nullptr, 256, pt.p, pt.valid};
+        float* base = SAVE ? a.save + (int64_t)(8 + 512 * l) * SP : nullptr;
+        return SaveRows{base, SAVE ? base + 256 * SP : nullptr, 256, pt.p, pt.valid};
     };
     const auto film_act = [&](int l, int slot_) {
         if constexpr (SAVE) {
-            float* base = a.save + (int64_t)(8 + 768 * l) * SP;
-            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, base, base + 256 * SP, base + 512 * SP, 256, pt.p,
-                                        pt.valid);
+            float* base = a.save + (int64_t)(8 + 512 * l) * SP;
+            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, base, base + 256 * SP, 256, pt.p, pt.valid);
         } else {
             activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h);
         }

@@ -89,10 +89,9 @@ struct BwdArgs {
     const float* raw;        // [P,4] forward outputs (rgb post-sigmoid, sigma post-ReLU)
     const float* g_raw;      // [P,4] dL/d(raw)
     int64_t points;
-    // FiLM kinds: one table per group of points_per_group consecutive points; per-tile partial sums of
-    // d gamma | d beta go to film_partial[layer][tile][wave][512]
+    // FiLM kinds: one table [9][512] per group of points_per_group consecutive points
     const float* film;
-    float* film_partial;
+    float* film_partial;     // unused by the chain (kept so the argument block stays stable)
     int64_t points_per_group, tiles_per_group, n_tiles;
 };
 
@@ -124,14 +123,21 @@ __device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 //                   latency sits under ~1000 MFMAs instead of stalling the one resident wave per SIMD;
 //   post(m, part) : dA = dX (.) act'(saved), written to HBM and left in X as the next layer's B operand.
 // B operands come from bsel; when the last K block reads X[j] with j < MB-1 pass a copy (post overwrites X[j]).
-enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2 };
+enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2, EPI_FILM = 3 };
 
-template <int KB, int MB, int NEXT_AUX, int NEXT_BLOCK, int EPI, bool SCALED, class BSel>
+// EPI_FILM: saved = C = 30 cos(30 u); writes dL/du = dX (.) C rows and leaves dA = gamma (.) dL/du in X; gamma is
+// this layer's FiLM row in LDS (`film_row`).  FILM layers also DMA the next epilogue's FiLM row (`next_film_layer`)
+// into the other film slot; `issue_slot` is the slot pair index handed to the stage issue (its aux / film
+// target is issue_slot ^ 1), `aux_slot` the slot the SCALED start row is read from.
+template <int KB, int MB, int NEXT_AUX, int NEXT_BLOCK, int EPI, bool SCALED, bool FILM = false, class BSel>
 __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float s, BSel bsel, f32x16 (&acc)[8],
                                           f32x16 (&X)[8], const float* __restrict__ saved, float* __restrict__ dA,
-                                          int64_t ld, int64_t p, bool valid) {
+                                          int64_t ld, int64_t p, bool valid, int issue_slot = -1,
+                                          int next_film_layer = 0, const float* film_row = nullptr) {
     const int h = c.h;
     const lds4_t pv = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
+    lds4_t pg = nullptr;
+    if constexpr (EPI == EPI_FILM) pg = lds_base(film_row + h * 4);
     const f32x4* srow = reinterpret_cast<const f32x4*>(saved + p * ld + 4 * h);
     f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
     f32x4 sv[EPI == EPI_LINEAR ? 1 : MB * 4];
@@ -147,18 +153,21 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
     };
     const auto post = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
-        f32x4 o;
+        f32x4 o, g;
+        if constexpr (EPI == EPI_FILM) g = pg[m * 8 + rg * 2];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float d = acc[m][4 * rg + q];
             if constexpr (EPI == EPI_RELU) o[q] = sv[m * 4 + rg][q] > 0.f ? d : 0.f;
-            else if constexpr (EPI == EPI_SIN) o[q] = sv[m * 4 + rg][q] * d;
+            else if constexpr (EPI == EPI_SIN || EPI == EPI_FILM) o[q] = sv[m * 4 + rg][q] * d;
             else o[q] = d;
-            X[m][4 * rg + q] = o[q];
+            if constexpr (EPI == EPI_FILM) X[m][4 * rg + q] = o[q] * g[q];
+            else X[m][4 * rg + q] = o[q];
         }
         if (valid) drow[m * 8 + rg * 2] = o;
     };
-    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, false, true>(c, aux_slot, 0, NoHook{}, bsel, acc, pre, post);
+    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
+                                                              NoHook{}, bsel, acc, pre, post);
 }
 
 // =========================================================================================
@@ -320,62 +329,47 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
 
 // =========================================================================================
 // FilmSirenNeRF backward chain (reverse of pi_GAN/modules.py:101-118).  Layer l: A = W x + b,
-// u = gamma A + beta, X = sin(30 u).  dL/du = dX (.) C;  d gamma = sum_p dL/du * A;  d beta = sum_p dL/du;
-// dA = dL/du * gamma.  The per-tile sums over the 32 points of each wave go to film_partial.
+// u = gamma A + beta, X = sin(30 u).  dL/du = dX (.) C is what the chain writes (grads region l); it carries
+// dA = gamma (.) dL/du to the next layer in registers.  d gamma / d beta / dW / db all come out of the per-image
+// sums T_g = sum_p dL/du X_{l-1}^T and s_g = sum_p dL/du (launch_field_backward), so the chain needs neither
+// the linear output A nor any cross-lane reduction.
 // =========================================================================================
 template <int MB>
-__device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ A,
-                                               const float* __restrict__ C, const float* __restrict__ gamma,
-                                               float* __restrict__ dA, float* __restrict__ part, int64_t p, bool valid,
-                                               int lane, int h) {
-    const f32x4* arow = reinterpret_cast<const f32x4*>(A + p * 256 + 4 * h);
+__device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ C,
+                                               const float* film_row, float* __restrict__ dU, int64_t p, bool valid,
+                                               int h) {
     const f32x4* crow = reinterpret_cast<const f32x4*>(C + p * 256 + 4 * h);
-    const f32x4* grow = reinterpret_cast<const f32x4*>(gamma + 4 * h);
-    f32x4* drow = reinterpret_cast<f32x4*>(dA + p * 256 + 4 * h);
-    const float live = valid ? 1.f : 0.f;
+    const lds4_t pg = lds_base(film_row + h * 4);
+    f32x4* drow = reinterpret_cast<f32x4*>(dU + p * 256 + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 av = arow[m * 8 + rg * 2], cv = crow[m * 8 + rg * 2], gv = grow[m * 8 + rg * 2];
-            f32x4 du, o, sg, sb;
+            const f32x4 cv = crow[m * 8 + rg * 2], gv = pg[m * 8 + rg * 2];
+            f32x4 du;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                du[q] = cv[q] * dX[m][4 * rg + q] * live;
-                o[q] = du[q] * gv[q];
-                X[m][4 * rg + q] = o[q];
-                sg[q] = du[q] * av[q];
-                sb[q] = du[q];
+                du[q] = cv[q] * dX[m][4 * rg + q];
+                X[m][4 * rg + q] = du[q] * gv[q];
             }
-            if (valid) drow[m * 8 + rg * 2] = o;
-            // sum over the 32 points of this lane half
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    sg[q] += __shfl_xor(sg[q], off);
-                    sb[q] += __shfl_xor(sb[q], off);
-                }
-            if ((lane & 31) == 0) {
-                *reinterpret_cast<f32x4*>(part + 32 * m + 8 * rg + 4 * h) = sg;
-                *reinterpret_cast<f32x4*>(part + 256 + 32 * m + 8 * rg + 4 * h) = sb;
-            }
+            if (valid) drow[m * 8 + rg * 2] = du;
         }
 }
 
 template <bool USE_DIR>
 __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    Ctx c = make_ctx_raw(smem, a.packed, nullptr);
-    const int64_t P = a.points;
-    issue_first_stage<4, 32, false>(c, 0, 0, 0);                 // rgb head rows x3, sigma row; K block 0 of hidden_layer_rgb^T
-
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;
+    Ctx c = make_ctx_raw(smem, a.packed, a.film + group * (kFilmLayers * kFilmRow));
+    const int64_t P = a.points;
+    // rgb head rows x3, sigma row; K blocks 0-1 of hidden_layer_rgb^T; FiLM rows 8 -> film slot 0, 7 -> slot 1
+    issue_first_stage<4, 32, true>(c, 0, 0, 8);
+    dma_lump<2>(c, c.frsrc, 7 * (kFilmRow * 4), kLdsFilm0 + kFilmRow);
+
     const int64_t local = tile * 128 + c.wave * 32 + (c.lane & 31);
     const bool valid = local < a.points_per_group;
     const int64_t p = group * a.points_per_group + (valid ? local : a.points_per_group - 1);
-    const float* film = a.film + group * (kFilmLayers * kFilmRow);
     const f32x4 g = reinterpret_cast<const f32x4*>(a.g_raw)[p];
     const f32x4 o = reinterpret_cast<const f32x4*>(a.raw)[p];
     const float d0 = g.x * o.x * (1.f - o.x), d1 = g.y * o.y * (1.f - o.y), d2 = g.z * o.z * (1.f - o.z);
@@ -384,14 +378,9 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
 
     f32x16 X[8], acc[8];
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
-    const auto zero = [&](f32x16 (&x)[8]) { init_zero<8>(x); };
-    // FiLM layer l: A at acts region 1+3l, C at 3+3l; dA at grads region l; partial row (l, tile, wave)
-    const auto layer_bwd = [&](int l) {
-        const float* base = a.acts + (int64_t)(8 + 768 * l) * P;
-        float* part = a.film_partial + (((int64_t)l * a.n_tiles + blockIdx.x) * 4 + c.wave) * 512;
-        film_bwd_store<8>(acc, X, base, base + 512 * P, film + l * kFilmRow, a.grads + (int64_t)(256 * l) * P, part, p,
-                          valid, c.lane, c.h);
-    };
+    const auto film_row = [&](int slot) { return smem + kLdsFilm0 + slot * kFilmRow; };
+    const auto C = [&](int l) { return a.acts + (int64_t)(8 + 512 * l + 256) * P; };
+    const auto dU = [&](int l) { return a.grads + (int64_t)(256 * l) * P; };
 
     __syncthreads();
     {   // dX_8 = W_rgb^T d_pre_rgb (256 features)
@@ -407,50 +396,52 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    layer_bwd(8);                                                                               // hidden_layer_rgb
-    mma_layer_fn<8, 8, 0, 0, 32, false>(
-        c, 0, 0, [&](f32x16 (&x)[8]) { init_scaled_vec<8>(smem + kLdsAux0, 3, c.h, ds, x); }, sel_x, acc);
+    film_bwd_store<8>(acc, X, C(8), film_row(0), dU(8), p, valid, c.h);                          // hidden_layer_rgb
+    // Chain layer j computes dX_j = W_{j+1}^T dA_{j+1}; its epilogue uses C_j and FiLM row j (film slot (8-j)&1) and
+    // it DMAs FiLM row j-1 into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
+    bwd_layer<8, 8, 0, 32, EPI_FILM, true, true>(c, 0, 3, ds, sel_x, acc, X, C(7), dU(7), 256, p, valid, 1, 6, film_row(1));
 #pragma unroll 1
-    for (int l = 7; l >= 2; --l) {                                                              // hidden_layers[6..1]
-        layer_bwd(l);
-        mma_layer_fn<8, 8, 0, 0, 32, false>(c, 0, 0, zero, sel_x, acc);
+    for (int j = 6; j >= 1; --j) {                                                               // hidden_layers[5..0]
+        const int fs = (8 - j) & 1;
+        bwd_layer<8, 8, 0, 32, EPI_FILM, false, true>(c, 0, 0, 0.f, sel_x, acc, X, C(j), dU(j), 256, p, valid, fs, j - 1,
+                                                      film_row(fs));
     }
-    layer_bwd(1);                                                                               // hidden_layers[0]
-    mma_layer_fn<8, 8, 0, 0, 0, false>(c, 0, 0, zero, sel_x, acc);
-    layer_bwd(0);                                                                               // input_layer
+    bwd_layer<8, 8, 0, 0, EPI_FILM, false, false>(c, 0, 0, 0.f, sel_x, acc, X, C(0), dU(0), 256, p, valid, 0, 0, film_row(0));  // input_layer
 }
 
-// d film[g][l][0:256] = sum over the group's tiles and waves of the gamma partials, [256:512] the beta ones.
-// Two levels, fixed order: level 1 sums kFilmRows-row chunks (grid = (chunks, groups, layers)) into a scratch
-// placed after the partials, level 2 sums the chunks.
-constexpr int kFilmRows = 64;
-
-__global__ __launch_bounds__(256) void film_reduce1_kernel(const float* __restrict__ part, int64_t n_tiles,
-                                                           int64_t tiles_per_group, float* __restrict__ tmp) {
-    const int l = blockIdx.z;
-    const int64_t g = blockIdx.y;
-    const int64_t rows = tiles_per_group * 4;
-    const int64_t r0 = (int64_t)blockIdx.x * kFilmRows;
-    const int64_t r1 = r0 + kFilmRows < rows ? r0 + kFilmRows : rows;
-    const float* src = part + (((int64_t)l * n_tiles + g * tiles_per_group) * 4) * 512;
-    const int64_t chunks = gridDim.x;
-    float* dst = tmp + (((int64_t)l * gridDim.y + g) * chunks + blockIdx.x) * 512;
-    for (int f = threadIdx.x; f < 512; f += 256) {
-        float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += src[r * 512 + f];
-        dst[f] = s;
+// FiLM layer finishing for ONE image (group) g.  T[f][k] = sum_{p in g} dL/du[p][f] X[p][k] (tk = 256, or the 3
+// raw-input columns), s[f] = sum_{p in g} dL/du[p][f].  Row f per workgroup, column k per thread:
+//   dW[f][col0+k]  (+)= gamma[f] T[f][k]                       (+= for g > 0: images are summed in order)
+//   d gamma_g[f]   (+)= sum_k W[f][col0+k] T[f][k]  (+ b[f] s[f] with the bias part: A = W x + b)
+//   d beta_g[f]      = s[f];   db[f] (+)= gamma[f] s[f]        (bias part only)
+__global__ __launch_bounds__(256) void film_finish_kernel(const float* __restrict__ T, int tk, const float* __restrict__ s,
+                                                          const float* __restrict__ W, int w_ld, int col0,
+                                                          const float* __restrict__ b, const float* __restrict__ film_row,
+                                                          int first_group, int bias_part, float* __restrict__ dW,
+                                                          float* __restrict__ db, float* __restrict__ dfilm_row) {
+    __shared__ float red[4];
+    const int f = blockIdx.x, k = threadIdx.x;
+    const float gamma = film_row[f];
+    float dot = 0.f;
+    if (k < tk) {
+        const float t = T[f * tk + k];
+        float* w = dW + (int64_t)f * w_ld + col0 + k;
+        *w = first_group ? gamma * t : *w + gamma * t;
+        dot = W[(int64_t)f * w_ld + col0 + k] * t;
     }
-}
-
-__global__ __launch_bounds__(256) void film_reduce2_kernel(const float* __restrict__ tmp, int64_t chunks,
-                                                           float* __restrict__ dfilm) {
-    const int l = blockIdx.y;
-    const int64_t g = blockIdx.x;
-    const float* src = tmp + (((int64_t)l * gridDim.x + g) * chunks) * 512;
-    for (int f = threadIdx.x; f < 512; f += 256) {
-        float s = 0.f;
-        for (int64_t k = 0; k < chunks; ++k) s += src[k * 512 + f];
-        dfilm[(g * kFilmLayers + l) * kFilmRow + f] = s;
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    if ((k & 63) == 0) red[k >> 6] = dot;
+    __syncthreads();
+    if (k == 0) {
+        float dg = ((red[0] + red[1]) + red[2]) + red[3];
+        if (bias_part) {
+            dg += b[f] * s[f];
+            dfilm_row[f] = dg;
+            dfilm_row[256 + f] = s[f];
+            db[f] = first_group ? gamma * s[f] : db[f] + gamma * s[f];
+        } else {
+            dfilm_row[f] += dg;
+        }
     }
 }
 
@@ -665,11 +656,9 @@ int64_t train_grads_floats(int kind) {
     }
     return -1;
 }
-// per-tile FiLM partial sums: [9 layers][tiles][4 waves][512]
-int64_t film_partial_floats(int64_t n_groups, int64_t points_per_group) {
-    const int64_t tpg = (points_per_group + 127) / 128;
-    const int64_t chunks = (tpg * 4 + kFilmRows - 1) / kFilmRows;
-    return (int64_t)kFilmLayers * n_groups * (tpg * 4 + chunks) * 512;
+// FiLM scratch: one image's T (256x256), its raw-input columns (256x3, padded) and column sums s (256)
+int64_t film_partial_floats(int64_t /*n_groups*/, int64_t /*points_per_group*/) {
+    return 256 * 256 + 256 * 4 + 256;
 }
 
 static int slab_points(int64_t P) {
@@ -796,7 +785,7 @@ static int run_k3(const float* xin, int c0, const float* dA, int lda, int F, int
 int launch_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads, const float* raw,
                           const float* g_raw, int64_t n_groups, int64_t points_per_group, const float* film,
                           float* film_partial, float* grad_film, float* partial, float* const* gp,
-                          hipStream_t stream) {
+                          const float* const* params, hipStream_t stream) {
     const int64_t P = n_groups * points_per_group;
     if (P <= 0) return 0;
     if (kind < 0 || kind > 4) { set_error("unknown field kind %d", kind); return -1; }
@@ -859,34 +848,55 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
         if ((rc = run_colsum(G(0), 256, 256, P, partial, gp[1], stream))) return rc;                                            // bias layers_pos.0
     } else if (kind == 2 || kind == 3) {
         const bool use_dir = kind == 2;
-        if (!film || !film_partial || !grad_film) { set_error("FiLM backward needs film, film_partial, grad_film"); return -1; }
+        if (!film || !film_partial || !grad_film || !params) {
+            set_error("FiLM backward needs film, the FiLM scratch, grad_film and the parameter pointers");
+            return -1;
+        }
         if (use_dir) hipLaunchKernelGGL(film_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
         else hipLaunchKernelGGL(film_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
         if ((rc = check_launch("film_bwd_kernel"))) return rc;
-        {
-            const int64_t chunks = (tpg * 4 + kFilmRows - 1) / kFilmRows;
-            float* tmp = film_partial + (int64_t)kFilmLayers * n_groups * tpg * 4 * 512;
-            hipLaunchKernelGGL(film_reduce1_kernel, dim3((unsigned)chunks, (unsigned)n_groups, kFilmLayers), dim3(256), 0,
-                               stream, film_partial, n_groups * tpg, tpg, tmp);
-            hipLaunchKernelGGL(film_reduce2_kernel, dim3((unsigned)n_groups, kFilmLayers), dim3(256), 0, stream, tmp,
-                               chunks, grad_film);
-        }
         constexpr RegionLayout AL = film_acts();
-        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
-        const auto G = [&](int l) { return grads + (int64_t)(256 * l) * P; };
-        // input_layer (K = 3)
-        if ((rc = run_k3(A(0), 0, G(0), 256, 256, P, partial, gp[0], 3, 0, stream))) return rc;
-        if ((rc = run_colsum(G(0), 256, 256, P, partial, gp[1], stream))) return rc;
-        for (int l = 1; l <= 7; ++l)             // hidden_layers[l-1]: input X_{l-1} = acts region 2 + 3(l-1)
-            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(2 + 3 * (l - 1)), 256, P, partial, gp[2 * l], 256, 0, 256, 256, gp[2 * l + 1], stream))) return rc;
-        // hidden_layer_rgb (param 9): [X_7 | dir]
+        const int64_t ppg = points_per_group;
+        float* T = film_partial;                 // [256][256] of the current image
+        float* T3 = T + 256 * 256;               // [256][3]
+        float* sg = T3 + 256 * 4;                // [256]
         const int ld9 = use_dir ? 259 : 256;
-        if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(23), 256, P, partial, gp[18], ld9, 0, 256, 256, gp[19], stream))) return rc;
-        if (use_dir && (rc = run_k3(A(0), 3, G(8), 256, 256, P, partial, gp[18], 259, 256, stream))) return rc;
-        // heads: sigma (param 8) on X_7, rgb (param 10) on X_8
+        // Per image g (fixed order, so the sums over images are deterministic): T_g, s_g of every FiLM layer, then
+        // dW += gamma_g (.) T_g, db += gamma_g (.) s_g, d gamma_g = <W, T_g> + b (.) s_g, d beta_g = s_g.
+        for (int64_t g = 0; g < n_groups; ++g) {
+            const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P + g * ppg * AL.width[r]; };
+            const auto G = [&](int l) { return grads + (int64_t)(256 * l) * P + g * ppg * 256; };
+            const float* frow = film + (g * kFilmLayers) * kFilmRow;
+            float* dfrow = grad_film + (g * kFilmLayers) * kFilmRow;
+            const int first = g == 0;
+            const auto finish = [&](const float* t, int tk, int l, int wp, int w_ld, int col0, int bias_part) {
+                hipLaunchKernelGGL(film_finish_kernel, dim3(256), dim3(256), 0, stream, t, tk, sg, params[2 * wp], w_ld, col0,
+                                   params[2 * wp + 1], frow + l * kFilmRow, first, bias_part, gp[2 * wp], gp[2 * wp + 1],
+                                   dfrow + l * kFilmRow);
+            };
+            // input_layer (K = 3): FiLM layer 0, parameter pair 0
+            if ((rc = run_k3(A(0), 0, G(0), 256, 256, ppg, partial, T3, 3, 0, stream))) return rc;
+            if ((rc = run_colsum(G(0), 256, 256, ppg, partial, sg, stream))) return rc;
+            finish(T3, 3, 0, 0, 3, 0, 1);
+            // hidden_layers[l-1] (FiLM layer l, parameter pair l): input X_{l-1} = acts region 1 + 2(l-1)
+            for (int l = 1; l <= 7; ++l) {
+                if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(1 + 2 * (l - 1)), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
+                finish(T, 256, l, l, 256, 0, 1);
+            }
+            // hidden_layer_rgb (FiLM layer 8, parameter pair 9): [X_7 | dir]
+            if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(15), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
+            finish(T, 256, 8, 9, ld9, 0, 1);
+            if (use_dir) {
+                if ((rc = run_k3(A(0), 3, G(8), 256, 256, ppg, partial, T3, 3, 0, stream))) return rc;
+                finish(T3, 3, 8, 9, 259, 256, 0);
+            }
+        }
+        if ((rc = check_launch("film_finish_kernel"))) return rc;
+        // heads: sigma (param pair 8) on X_7, rgb (pair 10) on X_8 - no FiLM in between, all images at once
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
         const float* dpre = grads + (int64_t)(9 * 256) * P;
-        if ((rc = run_head(dpre, 3, 1, A(23), 256, 256, P, partial, gp[16], gp[17], stream))) return rc;
-        if ((rc = run_head(dpre, 0, 3, A(26), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
+        if ((rc = run_head(dpre, 3, 1, A(15), 256, 256, P, partial, gp[16], gp[17], stream))) return rc;
+        if ((rc = run_head(dpre, 0, 3, A(17), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
     } else {
         hipLaunchKernelGGL(nerf_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
         if ((rc = check_launch("nerf_bwd_kernel"))) return rc;

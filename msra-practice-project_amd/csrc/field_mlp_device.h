@@ -98,8 +98,8 @@ __device__ __forceinline__ void issue_stage_slot(Ctx& c, int aux_slot, int chunk
     if constexpr (S == 0 && N_AUX > 0) {
         dma_lump<N_AUX>(c, c.rsrc, c.soff, kLdsAux0 + aux_slot * kLdsAux);
         c.soff += N_AUX * 1024;
-        if constexpr (FILM) dma_lump<2>(c, c.frsrc, film_layer * (kFilmRow * 4), kLdsFilm0 + aux_slot * kFilmRow);
     }
+    if constexpr (S == 0 && FILM) dma_lump<2>(c, c.frsrc, film_layer * (kFilmRow * 4), kLdsFilm0 + aux_slot * kFilmRow);
     constexpr int NP = N_CHUNK_PIECES / 4;        // pieces per wave
     static_assert(N_CHUNK_PIECES % 4 == 0, "K blocks are whole rounds of 4 pieces");
 #pragma unroll
@@ -230,22 +230,20 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
 }
 
 // Training flavour of the sin activations: besides X = sin(30 u) it stores, as [point][feature] rows, X and
-// the derivative factor C = 30 cos(30 u) (and for FiLM the linear output A, needed for d gamma).
+// the derivative factor C = 30 cos(30 u).
 template <int MB, int ACT>
 __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
-                                               float* __restrict__ a_rows, float* __restrict__ x_rows,
-                                               float* __restrict__ c_rows, int64_t ld, int64_t p, bool valid) {
+                                               float* __restrict__ x_rows, float* __restrict__ c_rows, int64_t ld, int64_t p, bool valid) {
     static_assert(ACT == ACT_SIN30 || ACT == ACT_FILM, "sin activations only");
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
-    f32x4* arow = reinterpret_cast<f32x4*>(a_rows + p * ld + 4 * h);
     f32x4* xrow = reinterpret_cast<f32x4*>(x_rows + p * ld + 4 * h);
     f32x4* crow = reinterpret_cast<f32x4*>(c_rows + p * ld + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            f32x4 g, b, xo, co, ao;
+            f32x4 g, b, xo, co;
             if constexpr (ACT == ACT_FILM) {
                 g = pf[m * 8 + rg * 2];
                 b = pf[64 + m * 8 + rg * 2];
@@ -257,12 +255,11 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
                 if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), b[q]);
                 const SinCos sc = hw_sincos30(u);
                 X[m][4 * rg + q] = sc.s;
-                xo[q] = sc.s; co[q] = 30.f * sc.c; ao[q] = v;
+                xo[q] = sc.s; co[q] = 30.f * sc.c;
             }
             if (valid) {
                 xrow[m * 8 + rg * 2] = xo;
                 crow[m * 8 + rg * 2] = co;
-                if constexpr (ACT == ACT_FILM) arow[m * 8 + rg * 2] = ao;
             }
         }
     }
@@ -314,10 +311,10 @@ __device__ __forceinline__ void mma_layer(Ctx& c, int aux_slot, int next_film_la
     mma_layer_fn<KB, MB, PAR0, NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot, next_film_layer, init, bsel, acc);
 }
 
-// Rows the training forward stores per layer (any may be null): A = linear output (FiLM), X = activation,
-// C = 30 cos(30 u) derivative factor (sin nets); all [point][ld] row-major.
+// Rows the training forward stores per layer (c may be null): X = activation, C = 30 cos(30 u) derivative
+// factor (sin nets); all [point][ld] row-major.
 struct SaveRows {
-    float* a; float* x; float* c;
+    float* x; float* c;
     int64_t ld, p;
     bool valid;
 };
@@ -349,7 +346,7 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     };
     const auto post = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
-        f32x4 g, bb, xo, co, ao;
+        f32x4 g, bb, xo, co;
         if constexpr (ACT == ACT_FILM) {
             g = pf[m * 8 + rg * 2];
             bb = pf[64 + m * 8 + rg * 2];
@@ -372,14 +369,13 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
                 }
             }
             X[m][4 * rg + q] = o;
-            xo[q] = o; ao[q] = v;
+            xo[q] = o;
         }
         if constexpr (SAVE) {
             if (sv.valid) {
                 const int64_t idx = m * 8 + rg * 2;    // float4 index inside the row (h folded into the row pointer)
                 reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[idx] = xo;
                 if constexpr (ACT == ACT_SIN30 || ACT == ACT_FILM) reinterpret_cast<f32x4*>(sv.c + sv.p * sv.ld + 4 * h)[idx] = co;
-                if constexpr (ACT == ACT_FILM) reinterpret_cast<f32x4*>(sv.a + sv.p * sv.ld + 4 * h)[idx] = ao;
             }
         }
     };

@@ -58,7 +58,7 @@ int64_t film_partial_floats(int64_t n_groups, int64_t points_per_group);
 int launch_field_backward(int kind, const float* packed_bwd, const float* acts, float* grads, const float* raw,
                           const float* g_raw, int64_t n_groups, int64_t points_per_group, const float* film,
                           float* film_partial, float* grad_film, float* partial, float* const* gp,
-                          hipStream_t stream);
+                          const float* const* params, hipStream_t stream);
 int launch_gen_rays(int width, int height, double focal, const float* c2w, int64_t ray0, int64_t n, float* rays,
                     int compute_f64, hipStream_t stream);
 int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float* z_lin, const float* t_rand,

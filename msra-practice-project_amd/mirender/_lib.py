@@ -52,8 +52,8 @@ SIGNATURES = {
     "mi_field_bwd_partial_floats": (_i64, [_i64]),
     "mi_field_eval_rays_train": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
     "mi_field_film_partial_floats": (_i64, [_i64, _i64]),
-    "mi_field_backward": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_vp), _int,
-                                 _vp, _vp]),
+    "mi_field_backward": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_vp),
+                                 ctypes.POINTER(_vp), _int, _vp, _vp]),
     "mi_event_create": (_vp, []),
     "mi_event_destroy": (None, [_vp]),
     "mi_event_record": (_int, [_vp, _vp]),

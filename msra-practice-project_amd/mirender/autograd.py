@@ -94,10 +94,12 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, acts=None
         part = torch.empty(lib.mi_field_bwd_partial_floats(pts), dtype=torch.float32, device=dev)
         out = [torch.empty_like(p) for p in pf.params]
         arr = (ctypes.c_void_p * len(out))(*[t.data_ptr() for t in out])
+        # FiLM kinds: d gamma = <W, dW_image> + b . db_image needs the parameters themselves
+        par = (ctypes.c_void_p * len(out))(*[p.data_ptr() for p in pf.params]) if f_all is not None else None
         with torch.cuda.device(dev):
             _lib.check(lib.mi_field_backward(pf.kind, _lib.ptr(packed_bwd), _lib.ptr(f_c), _lib.ptr(acts_c), _lib.ptr(gws),
                                              _lib.ptr(raw_c), _lib.ptr(g_raw[r0:r1]), ng, ppg, _lib.ptr(part),
-                                             _lib.ptr(fp), arr, len(out), _lib.ptr(g_c), stream), "mi_field_backward")
+                                             _lib.ptr(fp), arr, par, len(out), _lib.ptr(g_c), stream), "mi_field_backward")
         if total is None:
             total = out
         else:
