@@ -186,6 +186,46 @@ def test_render_image_c3_geometry_sample(nerf_render):
     assert stats(rgb, ref.rgb_f)[0] <= max(TOL, floor) and stats(acc, ref.acc_f)[0] <= max(TOL, floor)
 
 
+def test_render_image_c2_whole_frame(nerf_render):
+    """BASELINE config C2 (400x400, 64 coarse samples, Nf=0, fine_model is coarse_model): the whole frame in one
+    launch sequence.  Size-independent properties at full size: the aliased fine pass equals the coarse one (the
+    reference re-evaluates identical inputs, render.py:135-145), the frame does not depend on how the ray list is
+    split, white background where nothing is hit; a 1024-ray run against the oracle at 1e-4 (no resampling at
+    Nf=0, so the end-to-end gate is the hard one)."""
+    from mirender import render_core
+    W = H = 400
+    nc = 64
+    sd = synth.state_dict("nerf", seed=3, sharp=True, bias_jitter=0.05)
+    pose = synth.pose_degrees(4.0, 30.0, -30.0)
+    focal = 1.3875 * W
+    cm = model("nerf", sd)
+    tr_all = synth.t_rand(W * H, nc, seed=11)
+    with torch.no_grad():
+        whole = render_core._render_image_device(W, H, focal, pose, 2.0, 6.0, cm, cm, nc, 0, None, tr_all.to(dev()),
+                                                 None, 0, W * H)
+        cut = 400 * 123 + 77
+        a = render_core._render_image_device(W, H, focal, pose, 2.0, 6.0, cm, cm, nc, 0, None, tr_all[:cut].to(dev()),
+                                             None, 0, cut)
+        b = render_core._render_image_device(W, H, focal, pose, 2.0, 6.0, cm, cm, nc, 0, None, tr_all[cut:].to(dev()),
+                                             None, cut, W * H - cut)
+    for w, x, y in zip(whole, a, b):
+        assert torch.equal(w, torch.cat([x, y]))                      # shard-invariant, bit for bit
+    rgb, depth, acc = (t.cpu() for t in whole)
+    assert rgb.shape == (W * H, 3) and torch.isfinite(rgb).all() and float(rgb.min()) >= 0 and float(rgb.max()) <= 1 + 1e-5
+    empty = acc.reshape(-1) < 1e-6
+    if empty.any():                                                   # white background (render.py:101)
+        assert float((rgb[empty] - 1).abs().max()) <= 1e-5
+    ray0, n = 200 * W + 100, 1024
+    rays = R.rays_from_camera(W, H, focal, pose)[ray0:ray0 + n]
+    with torch.no_grad():
+        f = ofields.make_field("nerf", sd)
+        ref = R.render_rays(torch.from_numpy(rays), 2.0, 6.0, f, f, nc, 0, tr_all[ray0:ray0 + n])
+    assert torch.equal(ref.rgb_f, ref.rgb_c)                          # the oracle agrees the passes coincide
+    assert stats(rgb[ray0:ray0 + n], ref.rgb_f)[0] <= TOL
+    assert stats(acc[ray0:ray0 + n].reshape(-1), ref.acc_f)[0] <= TOL
+    assert stats(depth[ray0:ray0 + n].reshape(-1), ref.depth_f)[0] <= 5 * TOL    # depth scale 2..6
+
+
 def test_generic_callable_path(nerf_render):
     """Any callable f([M,6]) -> [M,4] (render.py:72-74): here a torch module unknown to the fused path."""
     torch.manual_seed(0)

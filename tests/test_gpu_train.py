@@ -239,7 +239,7 @@ def test_pigan_generator_batched_matches_per_image_and_trains():
         from mirender import render_core
         one = render_core.render_image_tensor(res, res, gen.renderer.focal, pose, 0.5, 1.5, gen.film_siren_nerf,
                                               gen.film_siren_nerf, nc, nf, t_rand=tr[i * res * res:(i + 1) * res * res])
-        assert float((one.permute(2, 0, 1) - img[i]).abs().max()) <= 1e-6
+        assert float((one.permute(2, 0, 1) - img[i]).detach().abs().max()) <= 1e-6
     img.square().mean().backward()
     g = [p.grad for p in gen.mapping_network.parameters()]
     assert all(x is not None and torch.isfinite(x).all() for x in g) and any(float(x.abs().max()) > 0 for x in g)
