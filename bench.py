@@ -138,7 +138,7 @@ def train_workload(args, world, rank, dev):
     (each rank its own batch = weak scaling) with one flat RCCL all-reduce of the renderer gradients.
       c4          pi_GAN generator step, 128x128, batch 32 per GPU, Nc=12 Nf=24 (BASELINE config C4)
       nerf_train  nerf/train_nerf.py step: 1024 rays per GPU, 64+128 samples, coarse+fine NeRF, Adam"""
-    from mirender import dist as mdist, fields, pigan, render_core
+    from mirender import dist as mdist, fields, pigan, render_core, train
     torch.manual_seed(rank)
     if args.workload == "c4":
         res, b, nc, nf = 128, 32, 12, 24
@@ -161,7 +161,7 @@ def train_workload(args, world, rank, dev):
         n, nc, nf = 1024, 64, 128
         coarse, fine = make_models(dev)
         params = list(coarse.parameters()) + list(fine.parameters())
-        opt = torch.optim.Adam(params, lr=5e-4)
+        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999), fused=True)     # train_nerf.py:96, one launch
         rays = torch.randn(n, 2, 3, device=dev)
         rays[:, 0] = torch.tensor([0.0, 0.0, 4.0], device=dev)
         rays[:, 1, 2] = -1.0
@@ -170,9 +170,8 @@ def train_workload(args, world, rank, dev):
         flops = rays_per_step * 3 * (nc + nc + nf) * fields.FLOPS_PER_POINT[fields.NERF]
 
         def step(i):
-            rgb_c, _, acc_c, rgb_f, _, acc_f = render_core.render_rays(rays, NEAR, FAR, coarse, fine, nc, nf, seed=i)
-            loss = sum(torch.mean((r - tgt[:, :3]) ** 2) + 0.1 * torch.mean((a - tgt[:, 3]) ** 2)
-                       for r, a in ((rgb_f, acc_f), (rgb_c, acc_c)))            # train_nerf.py:158-167
+            outs = render_core.render_rays(rays, NEAR, FAR, coarse, fine, nc, nf, seed=i)
+            loss, _psnr = train.nerf_loss(outs, tgt[:, :3], tgt[:, 3], use_alpha=True, use_fine_model=True)  # train_nerf.py:158-167
             opt.zero_grad(set_to_none=True)
             loss.backward()
             mdist.allreduce_grads(params)

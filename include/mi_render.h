@@ -188,6 +188,25 @@ int mi_image_metrics(const float* img1, const float* img2, int images, int chann
 int mi_grid_points(int n, const float* voxel_origin, float voxel_size, int64_t head, int64_t count, float* points,
                    void* stream);
 
+/* ---- nerf training-loop data path ------------------------------------ */
+
+/* nerf/train_nerf.py:158-167 in one pass over the batch: loss_x = mean((rgb_x - rgb)^2) [+ 0.1 mean((acc_x -
+ * alpha)^2) if use_alpha]; loss = loss_fine [+ loss_coarse if use_fine_model].  target [n,4] = (r,g,b,alpha)
+ * (batch[:, -4:]).  Writes the gradient seeds d loss / d(rgb_c [n,3], acc_c [n], rgb_f [n,3], acc_f [n]) that
+ * render_rays' backward consumes, and out[4] = {loss, mean((rgb_fine - rgb)^2) (psnr = -10 log10 of it),
+ * loss_coarse, loss_fine}.  workspace [mi_nerf_loss_workspace_floats(n)]. */
+int64_t mi_nerf_loss_workspace_floats(int64_t n);
+int mi_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float* rgb_f, const float* acc_f,
+                 const float* target, int use_alpha, int use_fine_model, float* g_rgb_c, float* g_acc_c,
+                 float* g_rgb_f, float* g_acc_f, float* workspace, float* out, void* stream);
+
+/* The rays_rgba batching table of nerf/train_nerf.py:78-82 built on the device: row image*H*W + pixel =
+ * (rays_o, rays_d of get_rays(width, height, focal, pose[image]), r, g, b, a); white_bkgd != 0 composites rgb on
+ * white first (rgb*a + 1 - a, train_nerf.py:64-68).  poses [images,12] = c2w[:3,:4] row-major (device),
+ * rgba [images,height,width,4] (device); out rays_rgba [images*height*width,10]. */
+int mi_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd,
+                int64_t images, float* rays_rgba, void* stream);
+
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 
 /* HIP events owned by the library's HIP runtime (the one the kernels launch on), so a host

@@ -279,6 +279,26 @@ int mi_grid_points(int n, const float* voxel_origin, float voxel_size, int64_t h
     return launch_grid_points(n, voxel_origin, voxel_size, head, count, points, (hipStream_t)stream);
 }
 
+int64_t mi_nerf_loss_workspace_floats(int64_t n) { return n > 0 ? nerf_loss_workspace_floats(n) : 0; }
+
+int mi_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float* rgb_f, const float* acc_f,
+                 const float* target, int use_alpha, int use_fine_model, float* g_rgb_c, float* g_acc_c, float* g_rgb_f,
+                 float* g_acc_f, float* workspace, float* out, void* stream) {
+    if (n <= 0 || !rgb_c || !acc_c || !rgb_f || !acc_f || !target || !g_rgb_c || !g_acc_c || !g_rgb_f || !g_acc_f ||
+        !workspace || !out) { set_error("mi_nerf_loss: bad arguments"); return MI_EINVAL; }
+    return launch_nerf_loss(n, rgb_c, acc_c, rgb_f, acc_f, target, use_alpha, use_fine_model, g_rgb_c, g_acc_c, g_rgb_f,
+                            g_acc_f, workspace, out, (hipStream_t)stream);
+}
+
+int mi_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd, int64_t images,
+                float* rays_rgba, void* stream) {
+    if (width <= 0 || height <= 0 || images < 0 || !poses || !rgba || (images > 0 && !rays_rgba)) {
+        set_error("mi_ray_bank: bad arguments");
+        return MI_EINVAL;
+    }
+    return launch_ray_bank(width, height, focal, poses, rgba, white_bkgd, images, rays_rgba, (hipStream_t)stream);
+}
+
 void* mi_event_create(void) {
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) { set_error("hipEventCreate failed"); return nullptr; }

@@ -1,11 +1,13 @@
-// eval_stages.hip - evaluation-side consumers/producers of the render path (gfx950), SURVEY.md 8(f) ranks 3-4.
+// eval_stages.hip - consumers/producers either side of the render path (gfx950), SURVEY.md 8(f) ranks 2-4.
 //
 //   image_metrics_kernel   mse + pytorch_ssim.ssim        reference nerf/test_nerf.py:102-105,
 //                                                          nerf/pytorch_ssim/__init__.py:12-37
 //   grid_points_kernel     voxel-grid query points        pi_GAN/utils.py:57-75 (create_mesh)
+//   nerf_loss_kernel       training loss + its gradient   nerf/train_nerf.py:158-167
+//   ray_bank_kernel        rays_rgba batching table       nerf/train_nerf.py:64-68, 78-82
 //
-// Both are HBM-bound streaming kernels next to a frame's 1.9e14 FLOP; they exist so a rendered frame is scored,
-// and a density grid is sampled, without leaving the device.  Compiled with -ffp-contract=off (un-fused mul/add
+// All are HBM-bound streaming kernels next to a frame's 1.9e14 FLOP; they exist so a rendered frame is scored, a
+// density grid is sampled and a training batch is assembled and scored without leaving the device.  Compiled with -ffp-contract=off (un-fused mul/add
 // like the torch ops they restate).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -156,6 +158,123 @@ int launch_grid_points(int N, const float* origin, float voxel_size, int64_t hea
     hipLaunchKernelGGL(grid_points_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, N, origin[0],
                        origin[1], origin[2], voxel_size, head, count, pts);
     return check_launch("grid_points");
+}
+
+// ---------------------------------------------------------------------------------------
+// nerf/train_nerf.py:158-167: loss_x = mean((rgb_x - rgb)^2) [+ 0.1 mean((acc_x - alpha)^2) if use_alpha],
+// loss = loss_fine [+ loss_coarse if use_fine_model]; psnr = -10 log10(mean((rgb_fine - rgb)^2)).
+// One pass writes the four gradient seeds d loss / d (rgb_c, acc_c, rgb_f, acc_f) and per-block partial sums
+// {se_rgb_c, se_acc_c, se_rgb_f, se_acc_f}; a one-block kernel adds them in fixed order (fp64) into
+// out = {loss, mse_rgb_fine, loss_coarse, loss_fine}.  target [n,4] = (r, g, b, alpha), as batch[:, -4:].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nerf_loss_kernel(int64_t n, const float* __restrict__ rgb_c,
+                                                        const float* __restrict__ acc_c, const float* __restrict__ rgb_f,
+                                                        const float* __restrict__ acc_f, const float* __restrict__ target,
+                                                        int use_alpha, int use_fine, float* __restrict__ g_rgb_c,
+                                                        float* __restrict__ g_acc_c, float* __restrict__ g_rgb_f,
+                                                        float* __restrict__ g_acc_f, float* __restrict__ partial) {
+    __shared__ float red[4][4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+        const float w_rgb = 2.f / (3.f * (float)n), w_acc = use_alpha ? 0.1f * 2.f / (float)n : 0.f;
+        const float wc = use_fine ? 1.f : 0.f;       // the coarse loss only counts with a separate fine model
+        const float a = target[i * 4 + 3];
+        const float dac = acc_c[i] - a, daf = acc_f[i] - a;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float t = target[i * 4 + k];
+            const float dc = rgb_c[i * 3 + k] - t, df = rgb_f[i * 3 + k] - t;
+            s[0] += dc * dc; s[2] += df * df;
+            g_rgb_c[i * 3 + k] = wc * w_rgb * dc;
+            g_rgb_f[i * 3 + k] = w_rgb * df;
+        }
+        s[1] = dac * dac; s[3] = daf * daf;
+        g_acc_c[i] = wc * w_acc * dac;
+        g_acc_f[i] = w_acc * daf;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        for (int off = 32; off > 0; off >>= 1) s[k] += __shfl_xor(s[k], off);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int k = threadIdx.x;
+        partial[(int64_t)blockIdx.x * 4 + k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
+    }
+}
+
+__global__ __launch_bounds__(256) void nerf_loss_reduce_kernel(const float* __restrict__ partial, int64_t blocks, int64_t n,
+                                                               int use_alpha, int use_fine, float* __restrict__ out) {
+    __shared__ double red[4][256];
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t b = threadIdx.x; b < blocks; b += 256)
+        for (int k = 0; k < 4; ++k) s[k] += partial[b * 4 + k];
+    for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mc = red[0][0] / (3.0 * n), mf = red[2][0] / (3.0 * n);
+        const double lc = mc + (use_alpha ? 0.1 * red[1][0] / n : 0.0), lf = mf + (use_alpha ? 0.1 * red[3][0] / n : 0.0);
+        out[0] = (float)(lf + (use_fine ? lc : 0.0));
+        out[1] = (float)mf;
+        out[2] = (float)lc;
+        out[3] = (float)lf;
+    }
+}
+
+int64_t nerf_loss_workspace_floats(int64_t n) { return ((n + 255) / 256) * 4; }
+
+int launch_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float* rgb_f, const float* acc_f,
+                     const float* target, int use_alpha, int use_fine, float* g_rgb_c, float* g_acc_c, float* g_rgb_f,
+                     float* g_acc_f, float* workspace, float* out, hipStream_t stream) {
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(nerf_loss_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, n, rgb_c, acc_c, rgb_f, acc_f, target,
+                       use_alpha, use_fine, g_rgb_c, g_acc_c, g_rgb_f, g_acc_f, workspace);
+    hipLaunchKernelGGL(nerf_loss_reduce_kernel, dim3(1), dim3(256), 0, stream, workspace, blocks, n, use_alpha, use_fine, out);
+    return check_launch("nerf_loss");
+}
+
+// ---------------------------------------------------------------------------------------
+// The batching table of nerf/train_nerf.py:78-82: row r = image*H*W + pixel holds (rays_o, rays_d, r, g, b, a)
+// with the rays of get_rays(width, height, focal, pose[image]) (all-fp32 arithmetic: focal is a Python float
+// there) and, as train_nerf.py:64-68 does for the training set, rgb composited on white: rgb*a + (1 - a).
+// poses [images][12] = c2w[:3,:4] row-major, rgba [images][H][W][4].  out [images*H*W][10].
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ray_bank_kernel(int width, int height, float focal, const float* __restrict__ poses,
+                                                       const float* __restrict__ rgba, int white_bkgd, int64_t n,
+                                                       float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int64_t hw = (int64_t)width * height;
+    const int64_t img = r / hw, pix = r % hw;
+    const float* m = poses + img * 12;
+    const float half_w = (float)width / 2.f, half_h = (float)height / 2.f;       // get_rays: width / 2 in Python floats
+    const float x = ((float)(pix % width) - half_w) / focal;
+    const float y = -((float)(pix / width) - half_h) / focal;
+    float* o = out + r * 10;
+    o[0] = m[3]; o[1] = m[7]; o[2] = m[11];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[3 + c] = (x * m[4 * c + 0] + y * m[4 * c + 1]) + (-1.f) * m[4 * c + 2];
+    const float* px = rgba + r * 4;
+    const float a = px[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[6 + c] = white_bkgd ? px[c] * a + (1.f - a) : px[c];
+    o[9] = a;
+}
+
+int launch_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd,
+                    int64_t images, float* out, hipStream_t stream) {
+    const int64_t n = images * width * height;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(ray_bank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, width, height, focal, poses,
+                       rgba, white_bkgd, n, out);
+    return check_launch("ray_bank");
 }
 
 }  // namespace mi

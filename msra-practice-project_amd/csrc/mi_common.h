@@ -72,6 +72,12 @@ int launch_image_metrics(const float* img1, const float* img2, int images, int c
                          const float* window, int window_size, float* workspace, float* out, hipStream_t stream);
 int launch_grid_points(int N, const float* origin, float voxel_size, int64_t head, int64_t count, float* pts,
                        hipStream_t stream);
+int64_t nerf_loss_workspace_floats(int64_t n);
+int launch_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float* rgb_f, const float* acc_f,
+                     const float* target, int use_alpha, int use_fine, float* g_rgb_c, float* g_acc_c, float* g_rgb_f,
+                     float* g_acc_f, float* workspace, float* out, hipStream_t stream);
+int launch_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd,
+                    int64_t images, float* out, hipStream_t stream);
 int launch_sample_pdf(int64_t n, int nb, int ns, const float* bins, const float* weights, const float* u_lin, float* out,
                       hipStream_t stream);
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,

@@ -1,0 +1,112 @@
+"""GPU parity of the nerf training-loop data path through the C ABI:
+the fused loss + gradient seed (nerf/train_nerf.py:158-167) against fixture F7 and the oracle's autograd, the
+device-built rays_rgba table (train_nerf.py:64-68, 78-82) bit-exact against the oracle, batching semantics, and
+one full step (RayBank -> render_rays -> nerf_loss -> backward) against the same step with the loss in torch ops."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import synth, train_ref as T  # noqa: E402
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def mi():
+    from mirender import _lib, fields, render_core, train
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    _lib.load()
+    return type("MI", (), {"fields": fields, "train": train, "render_core": render_core, "lib": _lib})
+
+
+def test_loss_golden_f7(mi, golden):
+    g = golden("nerf_grad_f7")
+    t = lambda k: torch.from_numpy(g[k]).to(dev())  # noqa: E731
+    tgt = t("target")
+    outs = (t("rgb_c"), None, t("acc_c"), t("rgb_f"), None, t("acc_f"))
+    loss, psnr = mi.train.nerf_loss(outs, tgt[:, :3], tgt[:, 3], use_alpha=True, use_fine_model=True)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    assert abs(float(psnr) + 10 * np.log10(float(((g["rgb_f"] - g["target"][:, :3]) ** 2).mean()))) <= 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 37, 256, 1024, 4099])
+@pytest.mark.parametrize("use_alpha,use_fine", [(False, True), (True, True), (True, False), (False, False)])
+def test_loss_and_seed_vs_oracle_autograd(mi, n, use_alpha, use_fine):
+    gen = torch.Generator().manual_seed(n)
+    cpu = [torch.rand(s, generator=gen).requires_grad_(True) for s in ((n, 3), (n,), (n, 3), (n,))]
+    tgt = torch.rand((n, 4), generator=gen)
+    ref_loss, ref_psnr = T.nerf_loss((cpu[0], None, cpu[1], cpu[2], None, cpu[3]), tgt[:, :3], tgt[:, 3], use_alpha, use_fine)
+    (ref_loss * 1.7).backward()
+    gpu = [c.detach().to(dev()).requires_grad_(True) for c in cpu]
+    loss, psnr = mi.train.nerf_loss((gpu[0], None, gpu[1], gpu[2], None, gpu[3]), tgt[:, :3].to(dev()), tgt[:, 3].to(dev()),
+                                    use_alpha, use_fine)
+    (loss * 1.7).backward()
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 2e-7 * max(1.0, abs(float(ref_loss.detach())))
+    assert abs(float(psnr.detach()) - float(ref_psnr.detach())) <= 1e-4
+    for a, b in zip(gpu, cpu):
+        want = torch.zeros_like(b) if b.grad is None else b.grad
+        assert float((a.grad.cpu() - want).abs().max()) <= 1e-7
+
+
+def test_ray_bank_bit_exact(mi):
+    W, H, n = 8, 6, 3
+    focal = 1.3875 * W
+    poses = np.stack([synth.pose_degrees(4.0, th, -30.0) for th in (37.0, -120.0, 5.0)]).astype(np.float32)
+    imgs = np.random.Generator(np.random.PCG64(3)).random((n, H, W, 4), dtype=np.float32)
+    for white in (True, False):
+        bank = mi.train.RayBank(imgs, poses, focal, dev(), white_bkgd=white)
+        exp = T.rays_rgba(imgs, poses, W, H, focal, white_bkgd=white)
+        assert np.array_equal(bank.table.cpu().numpy(), exp)
+
+
+def test_ray_bank_batches_and_epoch_reshuffle(mi):
+    W, H, n = 10, 7, 2
+    poses = np.stack([synth.pose_degrees(4.0, th, -30.0) for th in (0.0, 90.0)]).astype(np.float32)
+    imgs = np.random.Generator(np.random.PCG64(4)).random((n, H, W, 4), dtype=np.float32)
+    bank = mi.train.RayBank(imgs, poses, 1.3875 * W, dev())
+    ref = {tuple(r) for r in bank.table.cpu().numpy().round(6).tolist()}
+    bank.shuffle()
+    first = bank.table.clone()
+    bs = 32
+    seen = []
+    for _ in range(-(-len(bank) // bs)):                      # one epoch: ceil(140/32) = 5 batches, the last ragged
+        rays, rgb, alpha = bank.batch(bs)
+        assert rays.shape[1:] == (2, 3) and rgb.shape[1] == 3 and alpha.dim() == 1 and rays.shape[0] == rgb.shape[0] == alpha.shape[0]
+        seen.append(torch.cat([rays.reshape(-1, 6), rgb, alpha[:, None]], 1))
+    seen = torch.cat(seen)
+    assert seen.shape == first.shape and torch.equal(seen, first)          # the epoch walks the shuffled table once
+    assert {tuple(r) for r in seen.cpu().numpy().round(6).tolist()} == ref  # ... which is a permutation of the rows
+    assert bank.batch_idx == 0 and not torch.equal(bank.table, first)      # and the next epoch is reshuffled
+
+
+def test_one_training_step_matches_torch_loss(mi):
+    """RayBank -> render_rays -> fused loss -> backward == the same step with train_nerf.py:158-167 in torch ops."""
+    W, H = 12, 9
+    poses = np.stack([synth.pose_degrees(4.0, th, -30.0) for th in (20.0, -60.0)]).astype(np.float32)
+    imgs = np.random.Generator(np.random.PCG64(5)).random((2, H, W, 4), dtype=np.float32)
+    bank = mi.train.RayBank(imgs, poses, 1.3875 * W, dev(), generator=torch.Generator(device=dev()).manual_seed(1))
+    bank.shuffle()
+    rays, rgb, alpha = bank.batch(64)
+    cm = mi.fields.field_from_state_dict(synth.state_dict("nerf", seed=60, sharp=True, bias_jitter=0.05), dev())
+    fm = mi.fields.field_from_state_dict(synth.state_dict("nerf", seed=61, sharp=True, bias_jitter=0.05), dev())
+    params = list(cm.parameters()) + list(fm.parameters())
+    tr = synth.t_rand(64, 16, seed=2).to(dev())
+    grads = []
+    for fused in (True, False):
+        for p in params:
+            p.grad = None
+        outs = mi.render_core.render_rays(rays, 2.0, 6.0, cm, fm, 16, 24, t_rand=tr)
+        if fused:
+            loss, psnr = mi.train.nerf_loss(outs, rgb, alpha, use_alpha=True, use_fine_model=True)
+        else:
+            loss, psnr = T.nerf_loss(outs, rgb, alpha, use_alpha=True, use_fine_model=True)
+        loss.backward()
+        grads.append((float(loss.detach()), float(psnr.detach()), [p.grad.clone() for p in params]))
+    assert abs(grads[0][0] - grads[1][0]) <= 1e-6 and abs(grads[0][1] - grads[1][1]) <= 1e-4
+    for a, b in zip(grads[0][2], grads[1][2]):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+    assert mi.train.decayed_lr(5e-4, 500, 250000) == 5e-4 * 0.1 ** 0.5

@@ -198,3 +198,28 @@ def test_grid_samples_restatement():
     # non-cubic origin: x takes origin[2], z takes origin[0] (the reference's order)
     pts = G.grid_samples(3, voxel_origin=(1.0, 2.0, 3.0), voxel_size=0.5).numpy()
     assert pts[0].tolist() == [3.0, 2.0, 1.0] and pts[-1].tolist() == [4.0, 3.0, 2.0]
+
+
+def test_f7_train_loss_restatement(golden):
+    """nerf/train_nerf.py:158-167 restated (oracle/train_ref.py) on the reference's own render outputs of F7."""
+    from oracle import train_ref as T
+    g = golden("nerf_grad_f7")
+    t = lambda k: torch.from_numpy(g[k])  # noqa: E731
+    tgt = t("target")
+    outs = (t("rgb_c"), None, t("acc_c"), t("rgb_f"), None, t("acc_f"))
+    loss, psnr = T.nerf_loss(outs, tgt[:, :3], tgt[:, 3], use_alpha=True, use_fine_model=True)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-7
+    assert abs(float(psnr) + 10 * np.log10(float(((g["rgb_f"] - g["target"][:, :3]) ** 2).mean()))) <= 1e-4
+
+
+def test_rays_rgba_table_restatement(golden):
+    from oracle import train_ref as T
+    g = golden("rays_f1")
+    W, H, focal = int(g["W"]), int(g["H"]), float(g["focal"])
+    poses = np.stack([g["pose_nerf"], g["pose_nerf"]])
+    imgs = np.random.Generator(np.random.PCG64(3)).random((2, H, W, 4), dtype=np.float32)
+    tab = T.rays_rgba(imgs, poses, W, H, focal)
+    assert tab.shape == (2 * H * W, 10) and tab.dtype == np.float32
+    assert np.array_equal(tab[:H * W, 0:3], g["rays_o"].reshape(-1, 3)) and np.array_equal(tab[H * W:, 3:6], g["rays_d"].reshape(-1, 3))
+    a = imgs[..., 3:].reshape(-1, 1)
+    assert np.array_equal(tab[:, 6:9], imgs[..., :3].reshape(-1, 3) * a + (1. - a)) and np.array_equal(tab[:, 9:], a)
