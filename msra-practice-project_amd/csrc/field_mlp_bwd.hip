@@ -479,31 +479,33 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
     const int64_t step = 2 * KS * U;
     f32x4 av[U], an[U];
     bvec bv[U], bn[U];
-    const auto fetch = [&](int64_t t0, f32x4 (&a)[U], bvec (&b)[U]) {
+    const auto fetch1 = [&](int64_t t0, int u, f32x4& a, bvec& b) {
+        const int64_t p = t0 + 2 * KS * u + h;
+        if (p < p1) {
+            a = *reinterpret_cast<const f32x4*>(arow + p * lda);
+            b = *reinterpret_cast<const bvec*>(brow + p * ldx);
+        } else {
+            a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t p = t0 + 2 * KS * u + h;
-            if (p < p1) {
-                a[u] = *reinterpret_cast<const f32x4*>(arow + p * lda);
-                b[u] = *reinterpret_cast<const bvec*>(brow + p * ldx);
-            } else {
-                a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int d = 0; d < CB; ++d) b[u][d] = 0.f;
-            }
+            for (int d = 0; d < CB; ++d) b[d] = 0.f;
         }
     };
-    fetch(p0 + 2 * ks, av, bv);
+#pragma unroll
+    for (int u = 0; u < U; ++u) fetch1(p0 + 2 * ks, u, av[u], bv[u]);
     for (int64_t t0 = p0 + 2 * ks; t0 < p1; t0 += step) {
-        fetch(t0 + step, an, bn);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            // the next step's rows for this slot are requested between two groups of MFMAs (MFMA issue is in-order:
+            // a lump of 16 loads would idle the matrix pipe for its whole issue time)
+            fetch1(t0 + step, u, an[u], bn[u]);
+            __builtin_amdgcn_sched_barrier(0);
             bsum += av[u];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
                 for (int d = 0; d < CB; ++d)
                     acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
