@@ -146,13 +146,17 @@ __global__ __launch_bounds__(256) void composite_kernel(int64_t n, int S, const 
 }
 
 // ---------------------------------------------------------------------------------------
-// composite backward (autograd of raw_to_outputs, render.py:91-101): thread per ray, two sweeps.
-//   G_k = sum_c g_rgb[c]*(c_k[c]-1) + g_depth*z_k + g_acc        (dL/dw_k; rgb carries +1-acc)
-//   dL/dalpha_k = T_k * (G_k - S_k),  S_k = sum_{j>k} G_j alpha_j prod_{k<i<j} f_i
-//                 via the division-free recurrence S_k = G_{k+1} alpha_{k+1} + f_{k+1} S_{k+1}
+// composite backward (autograd of raw_to_outputs, render.py:91-101): G lanes per ray, lane = sample.
+//   Gk = sum_c g_rgb[c]*(c_k[c]-1) + g_depth*z_k + g_acc        (dL/dw_k; rgb carries +1-acc)
+//   dL/dalpha_k = T_k * (Gk - S_k),  S_k = sum_{j>k} Gj alpha_j prod_{k<i<j} f_i = R_{k+1} with the
+//                 division-free first-order recurrence R_k = Gk alpha_k + f_k R_{k+1}
 //   dL/dsigma_k = dL/dalpha_k * delta_k * (1-alpha_k);   dL/dc_k = g_rgb * w_k
 // f_k = 1-alpha_k+1e-10.  z and rays carry no gradient (z_samples is detached, render.py:141).
+// Sweep 1 (passes of G samples, front to back): the transmittance T_k as in composite_kernel (fp64 product
+// scan), parked in the output's .w slot.  Sweep 2 (back to front): R by a reverse scan of the affine maps
+// (f_k, Gk alpha_k) inside the pass, carried between passes.
 // ---------------------------------------------------------------------------------------
+template <int G>
 __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n, int S, const float* __restrict__ raw,
                                                             const float* __restrict__ z,
                                                             const float* __restrict__ rays,
@@ -160,39 +164,66 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n, int S, co
                                                             const float* __restrict__ g_depth,
                                                             const float* __restrict__ g_acc,
                                                             float* __restrict__ g_raw) {
-    const int64_t ray = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ray >= n) return;
-    const float* rd = rays + ray * 6 + 3;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (G - 1);
+    const int64_t ray = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+    const bool live = ray < n;
+    const int64_t rc = live ? ray : n - 1;
+    const float* rd = rays + rc * 6 + 3;
     const float nrm = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
-    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
-                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
-    const float gd = g_depth ? g_depth[ray] : 0.f, ga = g_acc ? g_acc[ray] : 0.f;
-    const float4* rw = reinterpret_cast<const float4*>(raw) + ray * S;
-    const float* zr = z + ray * S;
-    float4* out = reinterpret_cast<float4*>(g_raw) + ray * S;
-    // forward sweep: transmittance at every sample (kept in the output buffer's .w slot), fp64 product
+    const float gr = g_rgb ? g_rgb[rc * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[rc * 3 + 1] : 0.f,
+                gb = g_rgb ? g_rgb[rc * 3 + 2] : 0.f;
+    const float gd = g_depth ? g_depth[rc] : 0.f, ga = g_acc ? g_acc[rc] : 0.f;
+    const float4* rw = reinterpret_cast<const float4*>(raw) + rc * S;
+    const float* zr = z + rc * S;
+    float4* out = reinterpret_cast<float4*>(g_raw) + rc * S;
+    const int passes = (S + G - 1) / G;
     double T = 1.0;
-    for (int k = 0; k < S; ++k) {
-        const float delta = (k + 1 < S ? zr[k + 1] - zr[k] : 1e10f) * nrm;
-        const float alpha = 1.0f - expf(-rw[k].w * delta);
-        out[k].w = (float)T;
-        T *= (double)((1.0f - alpha) + 1e-10f);
+    for (int pass = 0; pass < passes; ++pass) {
+        const int k = pass * G + sub;
+        const bool in = k < S;
+        const int kc = in ? k : S - 1;
+        const float delta = (kc + 1 < S ? zr[kc + 1] - zr[kc] : 1e10f) * nrm;
+        const float alpha = in ? 1.0f - expf(-rw[kc].w * delta) : 0.f;
+        double p = in ? (double)((1.0f - alpha) + 1e-10f) : 1.0;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const double q = __shfl_up(p, o, G);
+            if (sub >= o) p *= q;
+        }
+        double excl = __shfl_up(p, 1, G);
+        if (sub == 0) excl = 1.0;
+        if (in && live) out[k].w = (float)(T * excl);
+        T = T * __shfl(p, G - 1, G);
     }
-    // reverse sweep
-    float Snext = 0.f;      // S_k for the sample being processed
-    for (int k = S - 1; k >= 0; --k) {
-        const float4 c = rw[k];
-        const float zk = zr[k];
-        const float delta = (k + 1 < S ? zr[k + 1] - zk : 1e10f) * nrm;
+    float carry = 0.f;                                   // R at the first sample of the pass behind this one
+    for (int pass = passes - 1; pass >= 0; --pass) {
+        const int k = pass * G + sub;
+        const bool in = k < S;
+        const int kc = in ? k : S - 1;
+        const float4 c = rw[kc];
+        const float zk = zr[kc];
+        const float delta = (kc + 1 < S ? zr[kc + 1] - zk : 1e10f) * nrm;
         const float e = expf(-c.w * delta);
         const float alpha = 1.0f - e;
-        const float f = (1.0f - alpha) + 1e-10f;
-        const float Tk = out[k].w;
-        const float w = alpha * Tk;
-        const float G = gr * (c.x - 1.f) + gg * (c.y - 1.f) + gb * (c.z - 1.f) + gd * zk + ga;
-        const float dalpha = Tk * (G - Snext);
-        out[k] = make_float4(gr * w, gg * w, gb * w, dalpha * delta * e);
-        Snext = G * alpha + f * Snext;
+        const float Tk = in && live ? out[kc].w : 0.f;
+        const float Gk = gr * (c.x - 1.f) + gg * (c.y - 1.f) + gb * (c.z - 1.f) + gd * zk + ga;
+        // affine map of this sample, R_k = A + M * R_{k+1}; composed towards higher lanes
+        float M = in ? (1.0f - alpha) + 1e-10f : 1.f, A = in ? Gk * alpha : 0.f;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const float M2 = __shfl_down(M, o, G), A2 = __shfl_down(A, o, G);
+            if (sub + o < G) { A = A + M * A2; M = M * M2; }
+        }
+        const float R = A + M * carry;                   // R_k
+        float Snext = __shfl_down(R, 1, G);              // S_k = R_{k+1}
+        if (sub == G - 1) Snext = carry;
+        carry = __shfl(R, 0, G);
+        if (in && live) {
+            const float w = alpha * Tk;
+            const float dalpha = Tk * (Gk - Snext);
+            out[k] = make_float4(gr * w, gg * w, gb * w, dalpha * delta * e);
+        }
     }
 }
 
@@ -376,8 +407,11 @@ int launch_composite(int64_t n, int S, const float* raw, const float* z, const f
 int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,
                          const float* g_depth, const float* g_acc, float* g_raw, hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, S, raw, z,
-                       rays, g_rgb, g_depth, g_acc, g_raw);
+    const int G = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
+    const dim3 grid((unsigned)((n * G + 255) / 256)), block(256);
+    if (G == 16) hipLaunchKernelGGL((composite_bwd_kernel<16>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_raw);
+    else if (G == 32) hipLaunchKernelGGL((composite_bwd_kernel<32>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_raw);
+    else hipLaunchKernelGGL((composite_bwd_kernel<64>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_raw);
     return check_launch("composite_bwd");
 }
 
