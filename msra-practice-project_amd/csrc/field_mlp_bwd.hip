@@ -448,13 +448,13 @@ __global__ __launch_bounds__(256) void film_finish_kernel(const float* __restric
 // =========================================================================================
 // dW GEMM over points.  A side: dA[p][a_col0 + 128*wm + 4*i + c], B side: X[p][x_col0 + 32*CB*wk + CB*j + d].
 // acc[c][d] (+)= A_c (x) B_d per point pair.  Workgroup = 4 waves = tiles (WM x WK) x k-split.
-// partial[(slab*KS + ks)][TM][TK] row-major, bias_partial[(slab*KS + ks)][TM].
+// partial record (slab*KS + ks) = [TM][TK] row-major tile, then (with_bias) the TM column sums of dA.
 // =========================================================================================
 template <int CB, int WM, int WK>
 __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict__ dA, int lda, int a_col0,
                                                          const float* __restrict__ X, int ldx, int x_col0,
                                                          int64_t P, int slab_pts, float* __restrict__ partial,
-                                                         float* __restrict__ bias_partial) {
+                                                         int with_bias) {
     constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
     typedef float bvec __attribute__((ext_vector_type(CB)));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
         for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
     }
     // write the partial tile: D[row i'][col j] on lane (j, h), reg r: i' = (r&3) + 8*(r>>2) + 4*h
-    float* out = partial + ((int64_t)blockIdx.x * KS + ks) * TM * TK;
+    float* out = partial + ((int64_t)blockIdx.x * KS + ks) * (TM * TK + (with_bias ? TM : 0));
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -522,11 +522,10 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
             for (int d = 0; d < CB; ++d) v[d] = acc[c][d][r];
             *reinterpret_cast<bvec*>(out + (int64_t)(128 * wm + 4 * ip + c) * TK + 32 * CB * wk + CB * i) = v;
         }
-    if (bias_partial && wk == 0) {
+    if (with_bias && wk == 0) {
         bsum.x += __shfl_xor(bsum.x, 32); bsum.y += __shfl_xor(bsum.y, 32);
         bsum.z += __shfl_xor(bsum.z, 32); bsum.w += __shfl_xor(bsum.w, 32);
-        if (h == 0)
-            *reinterpret_cast<f32x4*>(bias_partial + ((int64_t)blockIdx.x * KS + ks) * TM + 128 * wm + 4 * i) = bsum;
+        if (h == 0) *reinterpret_cast<f32x4*>(out + TM * TK + 128 * wm + 4 * i) = bsum;
     }
 }
 
@@ -552,6 +551,22 @@ __global__ __launch_bounds__(256) void reduce_level1_kernel(const float* __restr
     }
     for (; k < k1; ++k) s += src[(int64_t)k * stride4];
     reinterpret_cast<f32x4*>(tmp)[(int64_t)blockIdx.y * stride4 + idx4] = s;
+}
+
+// The same over records of rec_floats = TM*TK (+ TM bias sums): element idx < TM*TK goes to the weight gradient,
+// the tail (when bias_dst) to the bias gradient - one launch for both.
+__global__ void reduce_records_kernel(const float* __restrict__ partial, int n_partials, int rec_floats, int TM, int TK,
+                                      float* __restrict__ dst, int dst_ld, int dst_col0, int rows_valid, int cols_valid,
+                                      float* __restrict__ bias_dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rec_floats) return;
+    const bool is_bias = idx >= TM * TK;
+    const int row = is_bias ? idx - TM * TK : idx / TK, col = is_bias ? 0 : idx % TK;
+    if (row >= rows_valid || (!is_bias && col >= cols_valid) || (is_bias && !bias_dst)) return;
+    float s = 0.f;
+    for (int k = 0; k < n_partials; ++k) s += partial[(int64_t)k * rec_floats + idx];
+    if (is_bias) bias_dst[row] = s;
+    else dst[(int64_t)row * dst_ld + dst_col0 + col] = s;
 }
 
 // dst[row][dst_col0 + col] = sum over partials (fixed order), rows < rows_valid, cols < cols_valid
@@ -674,7 +689,7 @@ int64_t bwd_partial_floats(int64_t P) {
     const int64_t slabs = (P + slab - 1) / slab;
     const int64_t tiles = slabs * 4;                                   // up to 4 k-split partial tiles per slab
     const int64_t groups = (tiles + kReduceGroup - 1) / kReduceGroup;
-    return (tiles + groups) * (256 * 256) + tiles * 256 + 1024;        // partial tiles + level-1 sums + bias rows
+    return (tiles + groups) * (256 * 256 + 256) + 1024;                // partial records (tile + bias sums) + level-1 sums
 }
 
 // Sum `n` partial tiles of TM x TK (at `partial`, level-1 scratch at `tmp`) into dst.
@@ -706,12 +721,20 @@ static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P
     const int slab = slab_points(P);
     const int slabs = (int)((P + slab - 1) / slab);
     const int n = slabs * KS;
-    float* tmp = partial + (int64_t)n * TM * TK;                                      // level-1 sums
-    float* bias_partial = tmp + (int64_t)((n + kReduceGroup - 1) / kReduceGroup) * TM * TK;
+    const int rec = TM * TK + (gb ? TM : 0);                                          // tile (+ bias sums) per record
+    float* tmp = partial + (int64_t)n * rec;                                          // level-1 sums
     hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), 0, stream, dA, lda, 0, X, ldx, 0, P, slab,
-                       partial, gb ? bias_partial : nullptr);
-    reduce_tiles(partial, n, TM, TK, tmp, gw, w_ld, w_col0, rows_valid, cols_valid, stream);
-    if (gb) reduce_tiles(bias_partial, n, 1, TM, tmp, gb, TM, 0, 1, rows_valid, stream);
+                       partial, gb ? 1 : 0);
+    const float* src = partial;
+    int m = n;
+    if (m > kReduceGroup) {
+        const int groups = (m + kReduceGroup - 1) / kReduceGroup;
+        hipLaunchKernelGGL(reduce_level1_kernel, dim3((rec / 4 + 255) / 256, groups), dim3(256), 0, stream, src, m, rec, tmp);
+        src = tmp;
+        m = groups;
+    }
+    hipLaunchKernelGGL(reduce_records_kernel, dim3((rec + 255) / 256), dim3(256), 0, stream, src, m, rec, TM, TK, gw, w_ld,
+                       w_col0, rows_valid, cols_valid, gb);
     return check_launch("dw_gemm");
 }
 
