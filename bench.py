@@ -137,26 +137,37 @@ def train_workload(args, world, rank, dev):
     """Secondary workloads (not the headline line): one training step per `step`, data-parallel over ranks
     (each rank its own batch = weak scaling) with one flat RCCL all-reduce of the renderer gradients.
       c4          pi_GAN generator step, 128x128, batch 32 per GPU, Nc=12 Nf=24 (BASELINE config C4)
+      c5          pi_GAN training step, 256x256, batch 4 per GPU, Nc=24 Nf=48 (BASELINE config C5)
       nerf_train  nerf/train_nerf.py step: 1024 rays per GPU, 64+128 samples, coarse+fine NeRF, Adam"""
     from mirender import dist as mdist, fields, pigan, render_core, train
     torch.manual_seed(rank)
-    if args.workload == "c4":
-        res, b, nc, nf = 128, 32, 12, 24
+    if args.workload in ("c4", "c5"):
+        c5 = args.workload == "c5"
+        # C4: 128x128, batch 32 per GPU, Nc=12 Nf=24, generator step.  C5: 256x256, batch 4 per GPU (global 32 on 8
+        # GPUs), Nc=24 Nf=48, one whole training step = the D-step's generator forward (no grad, pi_GAN/train.py:108-111)
+        # + the G-step forward/backward (SURVEY.md 8d); the discriminator itself is stock PyTorch and not timed here.
+        res, b, nc, nf = (256, 4, 24, 48) if c5 else (128, 32, 12, 24)
         gen = pigan.Generator(256, res, near=0.5, far=1.5, fov=12, coarse_samples=nc, fine_samples=nf).to(dev)
         params = list(gen.parameters())
         opt = torch.optim.Adam(params, lr=5e-5, betas=(0.0, 0.9))
         z = torch.randn(b, 256, device=dev)
         rays_per_step = b * res * res
-        flops = rays_per_step * (nc + 3 * (nc + nf)) * fields.FLOPS_PER_POINT[fields.FILM_SIREN_NERF]
+        evals = (nc + 3 * (nc + nf)) + ((nc + nc + nf) if c5 else 0)
+        flops = rays_per_step * evals * fields.FLOPS_PER_POINT[fields.FILM_SIREN_NERF]
 
         def step(i):
+            if c5:
+                with torch.no_grad():
+                    gen(z, seed=500 + i)                                             # fake images for the D step
             img = gen(z, seed=100 + i)
             loss = torch.nn.functional.softplus(-img.mean(dim=(1, 2, 3))).mean()   # stand-in for -D(G(z))
             opt.zero_grad(set_to_none=True)
             loss.backward()
             mdist.allreduce_grads(params)
             opt.step()
-        name = "pi_GAN generator training step 128x128, batch 32/GPU, 12+24 samples (BASELINE config C4), fwd+bwd+Adam"
+        name = ("pi_GAN training step 256x256, batch 4/GPU, 24+48 samples (BASELINE config C5): D-step generator forward "
+                "+ G-step fwd+bwd+Adam, RCCL grad all-reduce" if c5 else
+                "pi_GAN generator training step 128x128, batch 32/GPU, 12+24 samples (BASELINE config C4), fwd+bwd+Adam")
     else:
         n, nc, nf = 1024, 64, 128
         coarse, fine = make_models(dev)
@@ -218,8 +229,8 @@ def main():
     ap.add_argument("--no-frame64", action="store_true",
                     help="skip the secondary 64-sample frame (profiling runs: keeps every nerf_fwd_kernel launch in the "
                          "trace one of the timed step's two launches, so rocprofv3's average matches roofline.avg_launch_ms)")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "nerf_train"],
-                    help="c3 (default, the headline line) | c4 | nerf_train (secondary training workloads)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5", "nerf_train"],
+                    help="c3 (default, the headline line) | c4 | c5 | nerf_train (secondary training workloads)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
