@@ -301,16 +301,6 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
     static_for<(KB + 1) / 2>(stage);
 }
 
-// forward flavour: accumulators start from the bias (+ the K=3 input columns) held in the layer's aux slot
-template <int KB, int MB, int PAR0, bool K3, int NEXT_AUX, int NEXT_CHUNK, bool FILM, class BSel>
-__device__ __forceinline__ void mma_layer(Ctx& c, int aux_slot, int next_film_layer, int k3_piece, float x, float y,
-                                          float z, BSel bsel, f32x16 (&acc)[8]) {
-    const auto init = [&](f32x16 (&a)[8]) {
-        init_acc<MB, K3>(c.smem + kLdsAux0 + aux_slot * kLdsAux, c.h, k3_piece, x, y, z, a);
-    };
-    mma_layer_fn<KB, MB, PAR0, NEXT_AUX, NEXT_CHUNK, FILM>(c, aux_slot, next_film_layer, init, bsel, acc);
-}
-
 // Rows the training forward stores per layer (c may be null): X = activation, C = 30 cos(30 u) derivative
 // factor (sin nets); all [point][ld] row-major.
 struct SaveRows {
@@ -382,27 +372,6 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
 }
 
-// acc = s * v[f] (v = VEC piece `piece` of an aux slot) or 0: starting values of the backward chain
-template <int MB>
-__device__ __forceinline__ void init_scaled_vec(const float* aux, int piece, int h, float s, f32x16 (&acc)[8]) {
-    const lds4_t p = lds_base(aux + h * 16);
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 w = p[piece * 64 + m * 8 + rg];
-            acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
-        }
-}
-
-template <int MB>
-__device__ __forceinline__ void init_zero(f32x16 (&acc)[8]) {
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-}
-
 // sigma / rgb heads: dot products over the features a lane holds + one cross-half add.
 template <int MB>
 __device__ __forceinline__ float head_dot(const f32x16 (&X)[8], const float* aux, int piece, int h) {
@@ -429,7 +398,7 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v
 // c < 3 -> sin(2^i x_c), else cos(2^i x_{c-3}) (nerf/nerf.py:44-49).  Register r of block blk holds feature
 // f0 = 32 blk + (r&3) + 8 (r>>2) on lane half 0 and f0 + 4 on half 1, so (frequency, component, sin|cos) are
 // compile-time constants per half and only a select on h remains at run time.  One v_sin per feature:
-// the argument goes to revolutions with a two-float product (as hw_sincos) and cos is sin shifted by 1/4 turn.
+// the argument goes to revolutions with a two-float product (as hw_frac30 does for the activations) and cos is sin shifted by 1/4 turn.
 __device__ __forceinline__ float pe_feature(float xv, float scale, float quarter) {
     const float c_hi = 0.15915494309189535f;                                    // 1 / (2 pi)
     const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
@@ -531,17 +500,5 @@ __device__ __forceinline__ void store_rows(float* __restrict__ base, int64_t ld,
             row[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
 }
 
-template <int MB>
-__device__ __forceinline__ void load_rows(const float* __restrict__ base, int64_t ld, int64_t p, int h,
-                                          f32x16 (&X)[8]) {
-    const f32x4* row = reinterpret_cast<const f32x4*>(base + p * ld + 4 * h);
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 t = row[m * 8 + rg * 2];
-            X[m][4 * rg + 0] = t.x; X[m][4 * rg + 1] = t.y; X[m][4 * rg + 2] = t.z; X[m][4 * rg + 3] = t.w;
-        }
-}
 
 }  // namespace mi

@@ -50,15 +50,6 @@ __device__ __forceinline__ float hw_frac30(float u) {
     const float lo = fmaf(u, c_hi, -hi) + u * c_lo;
     return __builtin_amdgcn_fractf(hi) + lo;
 }
-// same for a plain radian argument (positional encoding sin/cos(2^i x), nerf/nerf.py:47-48; |a| up to ~1e4)
-__device__ __forceinline__ SinCos hw_sincos(float a) {
-    const float c_hi = 0.15915494309189535f;                                    // 1 / (2 pi)
-    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
-    const float hi = a * c_hi;
-    const float lo = fmaf(a, c_hi, -hi) + a * c_lo;
-    const float f = __builtin_amdgcn_fractf(hi) + lo;
-    return {__builtin_amdgcn_sinf(f), __builtin_amdgcn_cosf(f)};
-}
 __device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(hw_frac30(u)); }
 __device__ __forceinline__ SinCos hw_sincos30(float u) {
     const float f = hw_frac30(u);
