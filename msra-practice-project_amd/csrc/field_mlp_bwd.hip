@@ -129,17 +129,27 @@ enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2, EPI_FILM = 3 };
 // this layer's FiLM row in LDS (`film_row`).  FILM layers also DMA the next epilogue's FiLM row (`next_film_layer`)
 // into the other film slot; `issue_slot` is the slot pair index handed to the stage issue (its aux / film
 // target is issue_slot ^ 1), `aux_slot` the slot the SCALED start row is read from.
-template <int KB, int MB, int NEXT_AUX, int NEXT_BLOCK, int EPI, bool SCALED, bool FILM = false, class BSel>
+// Row traffic is spread over the layer instead of bursting in one row (32 x 1 KiB per wave inside 2048 cycles
+// saturates the CU's vector-memory path and stalls the in-order wave): the saved-row quarter for part j is loaded
+// in mid slot 2(j%8) of K block j/8, and with DEFER the dA rows this layer produces are not stored by its own
+// epilogue but by the NEXT layer's mid slots 2(j%8)+1 (they sit unchanged in X, that layer's B operand, until its
+// last row) - PREV_MB blocks to `prev_dA`.  FiLM layers cannot defer (they store dL/du but carry gamma dL/du).
+template <int KB, int MB, int NEXT_AUX, int NEXT_BLOCK, int EPI, bool SCALED, bool FILM = false, bool DEFER = false,
+          int PREV_MB = 0, class BSel>
 __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float s, BSel bsel, f32x16 (&acc)[8],
                                           f32x16 (&X)[8], const float* __restrict__ saved, float* __restrict__ dA,
                                           int64_t ld, int64_t p, bool valid, int issue_slot = -1,
-                                          int next_film_layer = 0, const float* film_row = nullptr) {
+                                          int next_film_layer = 0, const float* film_row = nullptr,
+                                          float* __restrict__ prev_dA = nullptr, int64_t prev_ld = 0) {
+    static_assert(KB >= 4, "the mid slots of K blocks 0..3 carry the 32 row quarters");
+    static_assert(!(DEFER && EPI == EPI_FILM), "FiLM layers store dL/du, not what they carry on");
     const int h = c.h;
     const lds4_t pv = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
     lds4_t pg = nullptr;
     if constexpr (EPI == EPI_FILM) pg = lds_base(film_row + h * 4);
     const f32x4* srow = reinterpret_cast<const f32x4*>(saved + p * ld + 4 * h);
     f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
+    f32x4* prow = reinterpret_cast<f32x4*>(prev_dA + p * prev_ld + 4 * h);
     f32x4 sv[EPI == EPI_LINEAR ? 1 : MB * 4];
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
@@ -149,7 +159,17 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         } else {
             acc[m][4 * rg + 0] = 0.f; acc[m][4 * rg + 1] = 0.f; acc[m][4 * rg + 2] = 0.f; acc[m][4 * rg + 3] = 0.f;
         }
-        if constexpr (EPI != EPI_LINEAR) sv[m * 4 + rg] = srow[m * 8 + rg * 2];
+    };
+    const auto mid = [&](auto kbc, auto sc) {
+        constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
+        if constexpr (kb < 4 && slot < 16) {
+            if constexpr ((slot & 1) == 0) {
+                if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
+            } else if constexpr (j < PREV_MB * 4) {
+                constexpr int m = j / 4, rg = j % 4;
+                if (valid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+            }
+        }
     };
     const auto post = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
@@ -164,10 +184,10 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             if constexpr (EPI == EPI_FILM) X[m][4 * rg + q] = o[q] * g[q];
             else X[m][4 * rg + q] = o[q];
         }
-        if (valid) drow[m * 8 + rg * 2] = o;
+        if constexpr (!DEFER) { if (valid) drow[m * 8 + rg * 2] = o; }
     };
     mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
-                                                              NoHook{}, bsel, acc, pre, post);
+                                                              NoHook{}, bsel, acc, pre, post, mid);
 }
 
 // =========================================================================================
@@ -223,29 +243,30 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) Bd[m] = X[m];
         const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
-        bwd_layer<4, 8, 1, 32, EPI_LINEAR, false>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
+        bwd_layer<4, 8, 1, 32, EPI_LINEAR, false, false, true, 0>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
         slot ^= 1;
         // layers_dir[0]^T, plus the sigma head's contribution to dH8; dA7 = dH8 (.) [H8>0]
-        bwd_layer<8, 8, 0, 32, EPI_RELU, true>(c, slot, 0, ds, sel_x, acc, X, acts(8), grads(7), 256, p, valid);
+        bwd_layer<8, 8, 0, 32, EPI_RELU, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, acts(8), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
         slot ^= 1;
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(7), grads(6), 256, p, valid);  // L7^T
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(6), grads(5), 256, p, valid);  // L6^T
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(5), grads(4), 256, p, valid);  // L5^T (h part)
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(7), grads(6), 256, p, valid, -1, 0, nullptr, grads(7), 256);  // L7^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(6), grads(5), 256, p, valid, -1, 0, nullptr, grads(6), 256);  // L6^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(5), grads(4), 256, p, valid, -1, 0, nullptr, grads(5), 256);  // L5^T (h part)
 #pragma unroll 1
         for (int l = 4; l >= 2; --l)                                                           // L4^T .. L2^T
-            bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
-                                                    a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid);
-        bwd_layer<8, 8, 0, 0, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid);   // L1^T
+            bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
+                                                                    a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, -1, 0, nullptr,
+                                                                    a.grads + (int64_t)(256 * l) * P, 256);
+        bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
     } else {
         // dir layer^T with the sigma head's contribution to dH4 (sigma row is aux piece 3 of slot 0)
         f32x16 Bd[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) Bd[m] = X[m];
         const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
-        bwd_layer<4, 8, 0, 32, EPI_RELU, true>(c, 0, 3, ds, sel_d, acc, X, acts(4), grads(3), 256, p, valid);
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(3), grads(2), 256, p, valid);  // L3^T
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(1), 256, p, valid);  // L2^T
-        bwd_layer<8, 8, 0, 0, EPI_RELU, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid);   // L1^T
+        bwd_layer<4, 8, 0, 32, EPI_RELU, true, false, true, 0>(c, 0, 3, ds, sel_d, acc, X, acts(4), grads(3), 256, p, valid);
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(3), grads(2), 256, p, valid, -1, 0, nullptr, grads(3), 256);  // L3^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(1), 256, p, valid, -1, 0, nullptr, grads(2), 256);  // L2^T
+        bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
     }
 }
 
@@ -315,16 +336,17 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) Bd[m] = X[m];
         const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
-        bwd_layer<4, 8, 1, 32, EPI_LINEAR, false>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
+        bwd_layer<4, 8, 1, 32, EPI_LINEAR, false, false, true, 0>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
     }
     slot ^= 1;
     // layers_dir.0^T + sigma head; dA7 = dX8 (.) C8
-    bwd_layer<8, 8, 0, 32, EPI_SIN, true>(c, slot, 0, ds, sel_x, acc, X, acts(16), grads(7), 256, p, valid);
+    bwd_layer<8, 8, 0, 32, EPI_SIN, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, acts(16), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
 #pragma unroll 1
     for (int l = 7; l >= 2; --l)                                                                // L7^T .. L2^T: dA_{l-1} = dX_l (.) C_l
-        bwd_layer<8, 8, 0, 32, EPI_SIN, false>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(8 + 512 * (l - 1) + 256) * P,
-                                               a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid);
-    bwd_layer<8, 8, 0, 0, EPI_SIN, false>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(0), 256, p, valid);   // L1^T: dA0 = dX1 (.) C1
+        bwd_layer<8, 8, 0, 32, EPI_SIN, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(8 + 512 * (l - 1) + 256) * P,
+                                                               a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, -1, 0, nullptr,
+                                                               a.grads + (int64_t)(256 * l) * P, 256);
+    bwd_layer<8, 8, 0, 0, EPI_SIN, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T: dA0 = dX1 (.) C1
 }
 
 // =========================================================================================

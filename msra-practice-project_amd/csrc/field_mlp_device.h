@@ -118,16 +118,18 @@ __device__ __forceinline__ void issue_stage_slot(Ctx& c, int aux_slot, int chunk
 //     of the NEXT accumulator block, a quarter at a time - sits after each MFMA of block m's chain;
 //   * ORDER bit 1 (a layer's last K block): the last row runs m-major and post(m-1, part) - the activation of
 //     the block whose chain has just completed - rides one MFMA behind (its result lands 64 cycles after issue).
-// Other rows run q-major (MB independent accumulators round-robin).
+// Other rows run q-major (MB independent accumulators round-robin); rows 1-3 offer mid(kb, s), s = 0..3MB-1, one
+// slot per 4 MFMAs, for global loads / stores that must not arrive in a burst (the training kernels' row traffic:
+// 32 x 1 KiB per wave in one 2048-cycle row saturates the CU's 64 B/clk vector-memory path).
 struct NoHook {
     template <class A, class B> __device__ __forceinline__ void operator()(A, B) const {}
     template <class A> __device__ __forceinline__ void operator()(A) const {}
 };
 template <int I> using ic = std::integral_constant<int, I>;
 
-template <int MB, int ORDER, class Slot, class Pre, class Post>
+template <int MB, int ORDER, int KBI = 0, class Slot, class Pre, class Post, class Mid = NoHook>
 __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x16& b, f32x16 (&acc)[8], Slot slot,
-                                          Pre pre, Post post) {
+                                          Pre pre, Post post, Mid mid = Mid{}) {
     const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + c.lane;
     static_for<4>([&](auto rgc) {
         constexpr int rg = decltype(rgc)::value;
@@ -169,6 +171,10 @@ __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x
                     if constexpr (rg == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         slot(ic<q * (MB / 4) + g>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if constexpr (!std::is_same<Mid, NoHook>::value) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        mid(ic<KBI>{}, ic<(rg - 1) * 4 * (MB / 4) + q * (MB / 4) + g>{});
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 });
@@ -275,9 +281,9 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 // HOOKS: pre(m, part) / post(m, part) are the sliced bias preload / activation of mma_chunk; without them
 // init(acc) runs as one lump before the first MFMA and the caller applies its epilogue after the call.
 template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, bool HOOKS = false, class Init,
-          class BSel, class Pre = NoHook, class Post = NoHook>
+          class BSel, class Pre = NoHook, class Post = NoHook, class Mid = NoHook>
 __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film_layer, Init init, BSel bsel,
-                                             f32x16 (&acc)[8], Pre pre = Pre{}, Post post = Post{}) {
+                                             f32x16 (&acc)[8], Pre pre = Pre{}, Post post = Post{}, Mid mid = Mid{}) {
     static_assert(KB >= 2, "every MFMA layer has at least two K blocks");
     auto stage = [&](auto ic_) {
         constexpr int i = decltype(ic_)::value;
@@ -290,12 +296,12 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
         __syncthreads();
         if constexpr (i == 0 && !HOOKS) init(acc);
         const float* buf = c.smem + kLdsChunk0 + c.buf * kLdsChunk;
-        mma_chunk<MB, order0>(c, buf, bsel(ic<kb0>{}), acc, [&](auto sc) {
+        mma_chunk<MB, order0, kb0>(c, buf, bsel(ic<kb0>{}), acc, [&](auto sc) {
             constexpr int S = decltype(sc)::value;
             if constexpr (next_blocks > 0) issue_stage_slot<0, next_blocks * MB * 4, false, MB, S>(c, 0, c.buf ^ 1, 0);
             else issue_stage_slot<NEXT_AUX, 2 * NEXT_BLOCK, FILM, MB, S>(c, aux_slot ^ 1, c.buf ^ 1, next_film_layer);
-        }, pre, post);
-        if constexpr (two) mma_chunk<MB, order1>(c, buf + MB * 1024, bsel(ic<kb0 + 1>{}), acc, NoHook{}, pre, post);
+        }, pre, post, mid);
+        if constexpr (two) mma_chunk<MB, order1, kb0 + 1>(c, buf + MB * 1024, bsel(ic<kb0 + 1>{}), acc, NoHook{}, pre, post, mid);
         c.buf ^= 1;
     };
     static_for<(KB + 1) / 2>(stage);
