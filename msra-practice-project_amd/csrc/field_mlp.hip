@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     int slot = 0;
     MI_STAMP(a, 1);
     // layers_pos[0]: 60 -> 256
-    fwd_layer<2, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc, X, nullptr, rows(64, 256));
+    fwd_layer<2, 8, false, 1, 32, false, ACT_RELU, SAVE, true>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc, X, nullptr, rows(64, 256));
     slot ^= 1;                                                          // H1
     MI_STAMP(a, 3);
     float sigma;
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
 #ifdef MI_PROFILE_STAMPS
             if (l == 2 && a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;   // rows of layers_pos[2]: 32..64
 #endif
-            fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                 rows(64 + 256 * l, 256));   // H2..H5
+            fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                          rows(64 + 256 * l, 256), rows(64 + 256 * (l - 1), 256));   // H2..H5
             slot ^= 1;
             MI_ROW_STAMP(c);
 #ifdef MI_PROFILE_STAMPS
@@ -160,18 +160,18 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
             MI_STAMP(a, 3 + 2 * l);
         }
         // layers_pos[5]: [PE(60) | h(256)] -> 256
-        fwd_layer<10, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_skip, acc, X, nullptr,
-                                                              rows(region_offset(RL, 6), 256));   // H6
+        fwd_layer<10, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_skip, acc, X, nullptr,
+                                                                       rows(region_offset(RL, 6), 256), rows(region_offset(RL, 5), 256));   // H6
         slot ^= 1;
         MI_STAMP(a, 13);
         // layers_pos[6]
-        fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                             rows(region_offset(RL, 7), 256));    // H7
+        fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                      rows(region_offset(RL, 7), 256), rows(region_offset(RL, 6), 256));    // H7
         slot ^= 1;
         MI_STAMP(a, 15);
         // layers_pos[7] (+ sigma head pieces)
-        fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                             rows(region_offset(RL, 8), 256));    // H8
+        fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                      rows(region_offset(RL, 8), 256), rows(region_offset(RL, 7), 256));    // H8
         {
             const float* aux = smem + kLdsAux0 + slot * kLdsAux;
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
@@ -179,20 +179,20 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
         slot ^= 1;
         MI_STAMP(a, 17);
         // layers_dir[0]: linear
-        fwd_layer<8, 8, false, 5, 16, false, ACT_LINEAR, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                               rows(region_offset(RL, 9), 256));  // G
+        fwd_layer<8, 8, false, 5, 16, false, ACT_LINEAR, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                        rows(region_offset(RL, 9), 256), rows(region_offset(RL, 8), 256));  // G
         slot ^= 1;
         MI_STAMP(a, 19);
     } else {
         // layers_pos[1], [2], [3] (+ sigma head pieces), then the dir layer's 5 aux pieces
-        fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                             rows(region_offset(RL, 2), 256));
+        fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                      rows(region_offset(RL, 2), 256), rows(region_offset(RL, 1), 256));
         slot ^= 1;
-        fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                             rows(region_offset(RL, 3), 256));
+        fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                      rows(region_offset(RL, 3), 256), rows(region_offset(RL, 2), 256));
         slot ^= 1;
-        fwd_layer<8, 8, false, 5, 16, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                             rows(region_offset(RL, 4), 256));
+        fwd_layer<8, 8, false, 5, 16, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
+                                                                      rows(region_offset(RL, 4), 256), rows(region_offset(RL, 3), 256));
         {
             const float* aux = smem + kLdsAux0 + slot * kLdsAux;
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
@@ -200,8 +200,9 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
         slot ^= 1;
     }
     // layers_dir[1] (TinyNeRF: layers_dir[0]): [h(256) | PE_dir(24)] -> 128, relu; then rgb head
-    fwd_layer<9, 4, false, 0, 0, false, ACT_RELU, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_dir, acc, X, nullptr,
-                                                        rows(region_offset(RL, TINY ? 6 : 11), 128));   // H_d
+    fwd_layer<9, 4, false, 0, 0, false, ACT_RELU, SAVE, false, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_dir, acc, X, nullptr,
+                                                                  rows(region_offset(RL, TINY ? 6 : 11), 128),
+                                                                  rows(region_offset(RL, TINY ? 4 : 9), 256));   // H_d; G / H4 from X
     MI_STAMP(a, 20);
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 1, c.h) + aux[4 * kPiece + 0]);
@@ -256,27 +257,31 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     sin_act(1); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(l + 1));
+        SaveRows prev = sin_rows(l);
+        if (l == 1) prev.x = nullptr;                      // X_1 was stored by the K = 3 layer's own epilogue
+        fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(l + 1), prev);
         slot ^= 1;
     }
-    fwd_layer<8, 8, false, 4, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(5));  // layers_pos[4]
+    fwd_layer<8, 8, false, 4, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(5), sin_rows(4));  // layers_pos[4]
     slot ^= 1;
-    fwd_layer<8, 8, true, 1, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc, X, nullptr, sin_rows(6));  // [5]: [pos | h]
+    fwd_layer<8, 8, true, 1, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc, X, nullptr, sin_rows(6), sin_rows(5));  // [5]: [pos | h]
     slot ^= 1;
-    fwd_layer<8, 8, false, 3, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(7));  // [6]
+    fwd_layer<8, 8, false, 3, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(7), sin_rows(6));  // [6]
     slot ^= 1;
-    fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(8));  // [7] + sigma head
+    fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(8), sin_rows(7));  // [7] + sigma head
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
         sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
     }
     slot ^= 1;
-    fwd_layer<8, 8, false, 8, 16, false, ACT_LINEAR, SAVE>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                           SaveRows{SAVE ? region(17) : nullptr, nullptr, 256, pt.p, pt.valid});  // layers_dir[0] linear: G
+    const SaveRows g_rows{SAVE ? region(17) : nullptr, nullptr, 256, pt.p, pt.valid};
+    fwd_layer<8, 8, false, 8, 16, false, ACT_LINEAR, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, g_rows,
+                                                                    sin_rows(8));  // layers_dir[0] linear: G
     slot ^= 1;
-    fwd_layer<8, 4, true, 0, 0, false, ACT_SIN30, SAVE>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, nullptr,
-                                                        SaveRows{SAVE ? region(18) : nullptr, SAVE ? region(19) : nullptr, 128, pt.p, pt.valid});  // layers_dir[1]: [h | dir]
+    fwd_layer<8, 4, true, 0, 0, false, ACT_SIN30, SAVE, false, 8>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, nullptr,
+                                                                  SaveRows{SAVE ? region(18) : nullptr, SAVE ? region(19) : nullptr, 128, pt.p, pt.valid},
+                                                                  g_rows);  // layers_dir[1]: [h | dir]; G from X
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 4, c.h) + aux[7 * kPiece + 0]);
     const float g = sigmoidf(head_dot<4>(X, aux, 5, c.h) + aux[7 * kPiece + 1]);
@@ -330,19 +335,21 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     film_act(0, 0); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 5; ++l) {                                                   // hidden_layers[0..4]
-        fwd_layer<8, 8, false, 1, 32, true, ACT_FILM, SAVE>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(l));
+        SaveRows prev = film_rows(l - 1);
+        if (l == 1) prev.x = nullptr;                      // X_0 was stored by the input layer's own epilogue
+        fwd_layer<8, 8, false, 1, 32, true, ACT_FILM, SAVE, true, 8>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(l), prev);
         slot ^= 1;
     }
-    fwd_layer<8, 8, false, 3, 32, true, ACT_FILM, SAVE>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(6));  // hidden_layers[5]
+    fwd_layer<8, 8, false, 3, 32, true, ACT_FILM, SAVE, true, 8>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(6), film_rows(5));  // hidden_layers[5]
     slot ^= 1;
-    fwd_layer<8, 8, false, USE_DIR ? 8 : 5, 32, true, ACT_FILM, SAVE>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(7));  // hidden_layers[6]
+    fwd_layer<8, 8, false, USE_DIR ? 8 : 5, 32, true, ACT_FILM, SAVE, true, 8>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(7), film_rows(6));  // hidden_layers[6]
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
         sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
     }
     slot ^= 1;
-    fwd_layer<8, 8, USE_DIR, 0, 0, false, ACT_FILM, SAVE>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, film_row(slot), film_rows(8));   // hidden_layer_rgb
+    fwd_layer<8, 8, USE_DIR, 0, 0, false, ACT_FILM, SAVE, false, 8>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, film_row(slot), film_rows(8), film_rows(7));   // hidden_layer_rgb
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     constexpr int hp = USE_DIR ? 4 : 1;
     const float r = sigmoidf(head_dot<8>(X, aux, hp + 0, c.h) + aux[(hp + 3) * kPiece + 0]);

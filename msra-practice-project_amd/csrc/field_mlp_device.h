@@ -318,10 +318,15 @@ struct SaveRows {
 // One forward layer with the bias preload and the activation (+ training stores) sliced between the MFMAs of
 // its first / last K block.  X <- act(W . [inputs] + b); the layer's inputs may be X itself (in place: block m
 // of X is rewritten only after every K block that reads it has been consumed).
-template <int KB, int MB, bool K3, int NEXT_AUX, int NEXT_BLOCK, bool FILM, int ACT, bool SAVE, class BSel>
+// Training stores do not burst either: with DEFER_X this layer's X rows are written by the NEXT layer's mid slots
+// (slot 2(j%8)+1 of K block j/8 for quarter j; X is that layer's B operand and unchanged until its last row) - that
+// layer receives them as `prev` (PREV_MB blocks).  The derivative factor C of the sin nets is not kept in
+// registers, so it is still stored by the activation hook.
+template <int KB, int MB, bool K3, int NEXT_AUX, int NEXT_BLOCK, bool FILM, int ACT, bool SAVE, bool DEFER_X = false,
+          int PREV_MB = 0, class BSel>
 __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_layer, int k3_piece, float x, float y,
                                           float z, BSel bsel, f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row,
-                                          const SaveRows& sv) {
+                                          const SaveRows& sv, const SaveRows& prev = SaveRows{nullptr, nullptr, 0, 0, false}) {
     const int h = c.h;
     const lds4_t pb = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
     lds4_t pf = nullptr;
@@ -370,12 +375,28 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
         if constexpr (SAVE) {
             if (sv.valid) {
                 const int64_t idx = m * 8 + rg * 2;    // float4 index inside the row (h folded into the row pointer)
-                reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[idx] = xo;
+                if constexpr (!DEFER_X) reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[idx] = xo;
                 if constexpr (ACT == ACT_SIN30 || ACT == ACT_FILM) reinterpret_cast<f32x4*>(sv.c + sv.p * sv.ld + 4 * h)[idx] = co;
             }
         }
     };
-    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
+    if constexpr (SAVE && PREV_MB > 0) {
+        // a K block offers 3 * MB mid slots (2 * MB in the layer's last one): PPC quarters per K block on its odd slots
+        constexpr int PPC = MB >= 8 ? 8 : 4;
+        static_assert(KB * PPC >= PREV_MB * 4, "not enough K blocks to carry the previous layer's row quarters");
+        f32x4* prow = reinterpret_cast<f32x4*>(prev.x + prev.p * prev.ld + 4 * h);
+        const bool pvalid = prev.valid && prev.x != nullptr;
+        const auto mid = [&](auto kbc, auto sc) {
+            constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * PPC + slot / 2;
+            if constexpr (slot < 2 * PPC && (slot & 1) == 1 && j < PREV_MB * 4) {
+                constexpr int m = j / 4, rg = j % 4;
+                if (pvalid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+            }
+        };
+        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
+    } else {
+        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
+    }
 }
 
 // sigma / rgb heads: dot products over the features a lane holds + one cross-half add.
