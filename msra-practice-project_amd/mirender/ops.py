@@ -145,12 +145,14 @@ def field_eval_rays(pf: PackedField, rays: torch.Tensor, z: torch.Tensor, film=N
 
 
 class _Workspace:
-    """Grow-only per-device scratch for mi_render_rays (no allocation inside the library)."""
+    """Grow-only scratch for mi_render_rays (no allocation inside the library), one per (device, stream): launches
+    on one stream are ordered, so they can share it; concurrent callers (DataParallel's thread per GPU,
+    pi_GAN/train.py:50, or user threads on their own streams) never do."""
     bufs: dict = {}
 
     @classmethod
     def get(cls, device, nbytes):
-        key = str(device)
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         b = cls.bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -303,3 +303,43 @@ def test_reference_state_dict_layout_loads(nerf_render):
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_concurrent_threads_on_their_own_streams(nerf_render):
+    """DataParallel drives the renderer from one Python thread per replica; the library and the
+    binding keep no state that two callers could share (thread-local error/event slots, per-stream workspace).
+    Four threads render different ray sets concurrently on their own streams; each must match its serial result."""
+    import threading
+    from mirender import render_core
+    sd_c = synth.state_dict("nerf", seed=0, sharp=True, bias_jitter=0.05)
+    sd_f = synth.state_dict("nerf", seed=1, sharp=True, bias_jitter=0.05)
+    cm, fm = model("nerf", sd_c), model("nerf", sd_f)
+    jobs = []
+    for t in range(4):
+        n = 3000 + 517 * t
+        rays = torch.from_numpy(R.rays_from_camera(100, 100, 138.75, synth.pose_degrees(4.0, 40.0 * t, -30.0))[:n]).to(dev())
+        jobs.append((rays, synth.t_rand(n, 32, seed=t).to(dev())))
+    with torch.no_grad():
+        serial = [render_core.render_rays(r, 2.0, 6.0, cm, fm, 32, 48, t_rand=tr) for r, tr in jobs]
+    torch.cuda.synchronize()
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(3):
+                    o = render_core.render_rays(jobs[i][0], 2.0, 6.0, cm, fm, 32, 48, t_rand=jobs[i][1])
+                st.synchronize()
+            out[i] = o
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for a, b in zip(out, serial):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
