@@ -468,25 +468,50 @@ __global__ __launch_bounds__(256) void film_finish_kernel(const float* __restric
 }
 
 // =========================================================================================
-// dW GEMM over points.  A side: dA[p][a_col0 + 128*wm + 4*i + c], B side: X[p][x_col0 + 32*CB*wk + CB*j + d].
-// acc[c][d] (+)= A_c (x) B_d per point pair.  Workgroup = 4 waves = tiles (WM x WK) x k-split.
+// dW GEMM over points: dW[f][k] = sum_p dA[p][f] X[p][k].  Features sit on the MFMA lanes: lane i of wave-tile
+// (wm, wk) owns dA features 128*wm + 4*i + c (c = the four 32-wide row blocks) and X features 32*CB*wk + CB*i + d,
+// acc[c][d] (+)= A_c (x) B_d per point pair.  Workgroup = 4 waves = tiles (WM x WK) x k-split KS = 4 / (WM*WK).
 // partial record (slab*KS + ks) = [TM][TK] row-major tile, then (with_bias) the TM column sums of dA.
-// =========================================================================================
+// Rows are staged through LDS by DMA (buffer_load ... lds) rather than loaded per lane (the first version: 4 ms
+// of a 60 ms step slower):
+// a stage = 32 points = one contiguous run of rows of each operand ([point][feature] rows with lda == TM and
+// ldx == TK, which holds for every job), double-buffered; the next stage's 1 KiB pieces are issued one per 8
+// MFMAs during the first half of the current stage, so they have half a stage (>= 3 us) to land.  Rows past the
+// slab's end read as zero (buffer bounds), so ragged slabs need no masking.  Operand fetch is one ds_read_b128
+// (conflict-free: 16 consecutive lanes read 16 consecutive float4) per operand and point pair.
+constexpr int kGemmStagePts = 32;
+
 template <int CB, int WM, int WK>
-__global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict__ dA, int lda, int a_col0,
-                                                         const float* __restrict__ X, int ldx, int x_col0,
-                                                         int64_t P, int slab_pts, float* __restrict__ partial,
-                                                         int with_bias) {
-    constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
+__global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict__ dA, const float* __restrict__ X,
+                                                             int64_t P, int slab_pts, float* __restrict__ partial,
+                                                             int with_bias) {
+    constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK, T = kGemmStagePts;
+    constexpr int PA = T * TM / 256, PB = T * TK / 256;              // 1 KiB pieces per stage and operand
+    constexpr int NPW = (PA + PB + 3) / 4;                           // pieces per wave and stage
+    constexpr int STEPS = (T / 2) / KS;                              // point pairs per wave and stage
+    constexpr int PPS = (NPW + STEPS / 2 - 1) / (STEPS / 2);         // pieces issued per step in the first half
+    constexpr int STAGE = T * (TM + TK);                             // floats per stage buffer
     typedef float bvec __attribute__((ext_vector_type(CB)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 31, h = lane >> 5;
     const int tile = wave % TILES, ks = wave / TILES;
     const int wm = tile / WK, wk = tile % WK;
     const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
     const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
-    const float* arow = dA + a_col0 + 128 * wm + 4 * i;
-    const float* brow = X + x_col0 + 32 * CB * wk + CB * i;
+    const int n_stages = (int)((p1 - p0 + T - 1) / T);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(dA + p0 * TM), 0, (int)((p1 - p0) * TM * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(X + p0 * TK), 0, (int)((p1 - p0) * TK * 4), 0x00020000);
+    // piece q (0..PA+PB-1) of stage st into buffer b; wave w owns pieces w, w+4, ...
+    const auto issue = [&](int st, int b, int k) {
+        const int q = wave + 4 * k;
+        if (q < PA)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (MI_LDS void*)(smem + b * STAGE + q * 256), 16, lane * 16,
+                                                     st * (T * TM * 4) + q * 1024, 0, 0);
+        else if (q < PA + PB)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (MI_LDS void*)(smem + b * STAGE + T * TM + (q - PA) * 256), 16,
+                                                     lane * 16, st * (T * TK * 4) + (q - PA) * 1024, 0, 0);
+    };
 
     f32x16 acc[4][CB];
 #pragma unroll
@@ -497,40 +522,34 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict
             for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    constexpr int U = 8;    // point pairs per step; the next step's rows are loaded before this step's MFMAs (8192 MFMA cycles of lead)
-    const int64_t step = 2 * KS * U;
-    f32x4 av[U], an[U];
-    bvec bv[U], bn[U];
-    const auto fetch1 = [&](int64_t t0, int u, f32x4& a, bvec& b) {
-        const int64_t p = t0 + 2 * KS * u + h;
-        if (p < p1) {
-            a = *reinterpret_cast<const f32x4*>(arow + p * lda);
-            b = *reinterpret_cast<const bvec*>(brow + p * ldx);
-        } else {
-            a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int d = 0; d < CB; ++d) b[d] = 0.f;
-        }
-    };
-#pragma unroll
-    for (int u = 0; u < U; ++u) fetch1(p0 + 2 * ks, u, av[u], bv[u]);
-    for (int64_t t0 = p0 + 2 * ks; t0 < p1; t0 += step) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            // the next step's rows for this slot are requested between two groups of MFMAs (MFMA issue is in-order:
-            // a lump of 16 loads would idle the matrix pipe for its whole issue time)
-            fetch1(t0 + step, u, an[u], bn[u]);
-            __builtin_amdgcn_sched_barrier(0);
-            bsum += av[u];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
+    for (int k = 0; k < NPW; ++k) issue(0, 0, k);
+    for (int st = 0; st < n_stages; ++st) {
+        const int b = st & 1;
+        __syncthreads();                                             // stage st has landed (vmcnt(0) + barrier)
+        const float* As = smem + b * STAGE + 128 * wm + 4 * i;
+        const float* Bs = smem + b * STAGE + T * TM + 32 * CB * wk + CB * i;
+        const bool more = st + 1 < n_stages;
+        static_for<STEPS>([&](auto sc) {
+            constexpr int sidx = decltype(sc)::value;
+            const int j = 2 * (ks + KS * sidx) + h;
+            const f32x4 av = *reinterpret_cast<const f32x4*>(As + j * TM);
+            const bvec bv = *reinterpret_cast<const bvec*>(Bs + j * TK);
+            bsum += av;
+            static_for<4>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
 #pragma unroll
                 for (int d = 0; d < CB; ++d)
-                    acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][c], bv[u][d], acc[c][d], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+                    acc[c][d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], bv[d], acc[c][d], 0, 0, 0);
+                // first half of the stage: up to PPS pieces of the next stage per step, one after each group of CB MFMAs
+                constexpr int slot = sidx * PPS + c;
+                if constexpr (sidx < STEPS / 2 && c < PPS && slot < NPW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) issue(st + 1, b ^ 1, slot);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+        });
     }
     // write the partial tile: D[row i'][col j] on lane (j, h), reg r: i' = (r&3) + 8*(r>>2) + 4*h
     float* out = partial + ((int64_t)blockIdx.x * KS + ks) * (TM * TK + (with_bias ? TM : 0));
@@ -745,8 +764,15 @@ static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P
     const int n = slabs * KS;
     const int rec = TM * TK + (gb ? TM : 0);                                          // tile (+ bias sums) per record
     float* tmp = partial + (int64_t)n * rec;                                          // level-1 sums
-    hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), 0, stream, dA, lda, 0, X, ldx, 0, P, slab,
-                       partial, gb ? 1 : 0);
+    if (lda != TM || ldx != TK) { set_error("dw_gemm: rows must be dense (lda %d != %d or ldx %d != %d)", lda, TM, ldx, TK); return -1; }
+    constexpr size_t lds = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)dw_gemm_kernel<CB, WM, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) { set_error("hipFuncSetAttribute(dw_gemm) failed"); return -2; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), lds, stream, dA, X, P, slab, partial, gb ? 1 : 0);
     const float* src = partial;
     int m = n;
     if (m > kReduceGroup) {
