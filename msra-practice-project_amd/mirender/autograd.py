@@ -1,11 +1,11 @@
 """Differentiable render_rays: what PyTorch autograd provides in the reference (nerf/train_nerf.py:151-168,
 pi_GAN/modules.py:159-161), rebuilt on the HIP kernels.
 
-Forward = the inference kernels (nothing but the small per-sample tensors z / raw is kept).  Backward, per
-pass that received a gradient: compositing backward -> dL/d(raw); then, in chunks of rays so memory stays
-bounded whatever the batch, the field forward is re-run saving each layer's input, the backward chain
-produces every layer's dA, and the point-contraction GEMMs reduce them to the weight gradients
-(csrc/field_mlp_bwd.hip).  z_samples is detached like the reference (render.py:141), so the fine depths
+Forward = the training kernels, which also keep every layer's input, for as many ray ranges as the memory budget
+holds, and the inference kernels for the rest.  Backward, per pass that received a gradient: compositing
+backward -> dL/d(raw); then range by range (so memory stays bounded whatever the batch): the field forward is
+re-run if the range was not kept, the backward chain produces every layer's dA, and the point-contraction GEMMs
+reduce them to the weight gradients (csrc/field_mlp_bwd.hip).  z_samples is detached like the reference (render.py:141), so the fine depths
 carry no gradient into the coarse pass.
 """
 from __future__ import annotations
@@ -16,8 +16,9 @@ import torch
 
 from . import _lib, fields, ops
 
-CHUNK_BYTES = 48 << 30             # saved activations + per-layer gradients per backward chunk (288 GB of HBM)
-SAVE_IN_FORWARD_BYTES = 48 << 30   # keep layer inputs from the forward when they fit (no recompute in backward)
+CHUNK_BYTES = 48 << 30         # saved activations + per-layer gradients per ray range (288 GB of HBM)
+SAVE_COARSE_BYTES = 48 << 30   # layer inputs the forward may keep for the coarse pass (no recompute in backward) ...
+SAVE_FINE_BYTES = 160 << 30    # ... and for the fine pass; both also limited to half of the free memory
 
 
 def _max_points_per_chunk(pf) -> int:
@@ -51,33 +52,65 @@ def _forward_saving(pf: fields.PackedField, rays, z, film):
     return raw, acts
 
 
-def _can_save(pf: fields.PackedField, n_points: int) -> bool:
+def _chunk_ranges(pf: fields.PackedField, n: int, s: int, film):
+    """The pass split into ray ranges whose saved activations + gradients fit CHUNK_BYTES (whole FiLM groups per
+    range).  Forward and backward use the same split, so a range saved in the forward is found again."""
+    f_all, groups, rpg = _groups(pf, film, n)
+    if f_all is not None:
+        step = max(1, _max_points_per_chunk(pf) // (rpg * s)) * rpg
+    else:
+        step = max(1, _max_points_per_chunk(pf) // s)
+    return f_all, rpg, [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
+
+
+def _save_budget(dev, cap: int) -> int:
+    """Bytes of layer inputs the forward may keep: `cap`, but never more than half of what is free right now."""
+    free, _total = torch.cuda.mem_get_info(dev)
+    return max(0, min(cap, free // 2))
+
+
+def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothing: bool = False):
+    """raw [n,S,4] of the pass, plus {range index: saved layer inputs} for as many leading ranges as the budget
+    holds (with all_or_nothing: for every range or for none); the rest is evaluated by the plain kernel and
+    recomputed range by range in backward."""
     lib = _lib.load()
-    a = lib.mi_field_train_acts_floats(pf.kind)
-    return a > 0 and 4 * a * n_points <= SAVE_IN_FORWARD_BYTES
+    n, s = z.shape
+    per_point = 4 * lib.mi_field_train_acts_floats(pf.kind)
+    f_all, rpg, ranges = _chunk_ranges(pf, n, s, film)
+    budget = _save_budget(pf.device, cap)
+    if all_or_nothing and per_point * n * s > budget:
+        budget = 0
+    saved, parts, r_done = {}, [], 0
+    for k, (r0, r1) in enumerate(ranges):
+        need = per_point * (r1 - r0) * s
+        if need > budget:
+            break
+        f_c = None if f_all is None else f_all[r0 // rpg:r1 // rpg]
+        raw_k, saved[k] = _forward_saving(pf, rays[r0:r1], z[r0:r1], f_c)
+        parts.append(raw_k)
+        budget -= need
+        r_done = r1
+    if r_done < n:
+        f_c = None if f_all is None else f_all[r_done // rpg:]
+        parts.append(ops.field_eval_rays(pf, rays[r_done:], z[r_done:], f_c))
+    return (parts[0] if len(parts) == 1 else torch.cat(parts)), saved
 
 
-def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, acts=None):
+def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=None):
     """Gradients of one pass: (list of tensors shaped like pf.params, grad of the FiLM table or None).
-    `acts` = layer inputs kept by the forward; without them the forward is re-run chunk by chunk (whole
-    FiLM groups per chunk) so memory stays bounded."""
+    `saved` = {range index: layer inputs kept by the forward}; the other ranges re-run the forward first, so
+    memory stays bounded whatever the batch."""
     lib = _lib.load()
     dev = pf.device
-    acts_f, grads_f = lib.mi_field_train_acts_floats(pf.kind), lib.mi_field_train_grads_floats(pf.kind)
+    grads_f = lib.mi_field_train_grads_floats(pf.kind)
     n, s = z.shape
-    f_all, groups, rpg = _groups(pf, film, n)
-    if acts is not None:
-        groups_per_chunk = groups
-    else:
-        groups_per_chunk = max(1, _max_points_per_chunk(pf) // (rpg * s)) if f_all is not None else 1
-    rays_per_chunk = groups_per_chunk * rpg if f_all is not None else (n if acts is not None else
-                                                                        max(1, _max_points_per_chunk(pf) // s))
+    f_all, rpg, ranges = _chunk_ranges(pf, n, s, film)
+    saved = {} if saved is None else saved
     total = None
     g_film = None if f_all is None else torch.empty_like(f_all)
     packed_bwd = pf.refresh_bwd()
     stream = _lib.stream_ptr(dev)
-    for r0 in range(0, n, rays_per_chunk):
-        r1 = min(n, r0 + rays_per_chunk)
+    for k, (r0, r1) in enumerate(ranges):
         pts = (r1 - r0) * s
         f_c = g_c = fp = None
         ng, ppg = 1, pts
@@ -86,8 +119,8 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, acts=None
             ppg = rpg * s
             f_c, g_c = f_all[r0 // rpg:r0 // rpg + ng], g_film[r0 // rpg:r0 // rpg + ng]
             fp = torch.empty(lib.mi_field_film_partial_floats(ng, ppg), dtype=torch.float32, device=dev)
-        if acts is not None:
-            acts_c, raw_c = acts, raw
+        if k in saved:
+            acts_c, raw_c = saved.pop(k), raw[r0:r1]
         else:
             raw_c, acts_c = _forward_saving(pf, rays[r0:r1], z[r0:r1], f_c)
         gws = torch.empty(grads_f * pts, dtype=torch.float32, device=dev)
@@ -100,6 +133,7 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, acts=None
             _lib.check(lib.mi_field_backward(pf.kind, _lib.ptr(packed_bwd), _lib.ptr(f_c), _lib.ptr(acts_c), _lib.ptr(gws),
                                              _lib.ptr(raw_c), _lib.ptr(g_raw[r0:r1]), ng, ppg, _lib.ptr(part),
                                              _lib.ptr(fp), arr, par, len(out), _lib.ptr(g_c), stream), "mi_field_backward")
+        del acts_c
         if total is None:
             total = out
         else:
@@ -127,17 +161,12 @@ class _RenderRaysFn(torch.autograd.Function):
         dev = pf_c.device
         n = rays.shape[0]
         z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed)
-        ctx.acts_c = ctx.acts_f = None
-        if _can_save(pf_c, n * nc):
-            raw_c, ctx.acts_c = _forward_saving(pf_c, rays, z_c, film)
-        else:
-            raw_c = ops.field_eval_rays(pf_c, rays, z_c, film)
+        # the coarse pass often gets no gradient at all (pi_GAN trains through rgb_fine only): keep its layer inputs
+        # only when they are small; the fine pass may keep as many ranges as half the free HBM holds
+        raw_c, ctx.acts_c = _forward_pass(pf_c, rays, z_c, film, SAVE_COARSE_BYTES, all_or_nothing=True)
         rgb_c, depth_c, acc_c, w_c = ops.composite(raw_c, z_c, rays)
         z_f = ops.sample_fine(z_c, w_c, near, far, nf)
-        if _can_save(pf_f, n * (nc + nf)):
-            raw_f, ctx.acts_f = _forward_saving(pf_f, rays, z_f, film)
-        else:
-            raw_f = ops.field_eval_rays(pf_f, rays, z_f, film)
+        raw_f, ctx.acts_f = _forward_pass(pf_f, rays, z_f, film, SAVE_FINE_BYTES)
         rgb_f, depth_f, acc_f, _ = ops.composite(raw_f, z_f, rays, want_weights=False)
         ctx.pf_c, ctx.pf_f, ctx.film = pf_c, pf_f, None if film is None else film.detach()
         ctx.n_c = len(pf_c.params)

@@ -158,10 +158,11 @@ def test_field_grads_vs_oracle_autograd_injected(kind, n, nc, nf, sharp):
         assert e_hip <= max(5e-4 if smooth else 5e-3, 3 * e_cpu), (name, e_hip, e_cpu)
         tight += e_hip <= 3e-4
     assert tight >= len(pairs) // 2          # most tensors see no flip at all and agree to fp32 rounding
-    # chunked recompute path gives the same gradients as the saved-activation path
+    # the recompute path (above: nothing kept) gives the same gradients as the kept-activation path
     if not is_film:
-        raw_s, acts = A._forward_saving(pf, rays_d, z_d, film_d)
-        got2, _ = A._field_backward(pf, rays_d, z_d, raw_s, g_raw, film_d, acts)
+        raw_s, saved = A._forward_pass(pf, rays_d, z_d, film_d, 1 << 40)
+        assert saved and torch.equal(raw_s, raw_d)
+        got2, _ = A._field_backward(pf, rays_d, z_d, raw_s, g_raw, film_d, saved)
         for a_, b_ in zip(got, got2):
             assert torch.equal(a_, b_)
 
@@ -259,3 +260,34 @@ def test_pigan_generator_batched_matches_per_image_and_trains():
     np.random.seed(3)
     pose = gen.renderer.sample_pose()
     assert np.array_equal(pose, pigan.camera_pos_to_transform_matrix(1, a[0], a[1]))
+
+
+@pytest.mark.parametrize("kind", ["nerf", "film_siren_nerf"])
+def test_partial_save_and_recompute_give_the_same_gradients(kind, monkeypatch):
+    """The forward keeps layer inputs for as many ray ranges as its budget holds and backward recomputes the rest:
+    all kept, none kept and a mix must agree (the split into ranges is the same in all three, so the sums are too)."""
+    from mirender import autograd, fields, render_core
+    sd = synth.state_dict(kind, seed=33)
+    m = fields.field_from_state_dict(sd, dev())
+    film = synth.film_params(4, seed=2).to(dev()).requires_grad_(True) if kind.startswith("film") else None
+    n, nc, nf = 4 * 96, 8, 16
+    rays = torch.from_numpy(R.rays_from_camera(24, 16, 33.3, synth.pose_degrees(4.0 if film is None else 1.0, 20.0, -30.0))[:n]).to(dev())
+    near, far = (2.0, 6.0) if film is None else (0.5, 1.5)
+    tr = synth.t_rand(n, nc, seed=5).to(dev())
+    lib_acts = 4 * autograd._lib.load().mi_field_train_acts_floats(fields.as_packed_field(m).kind)
+    per_range = 96 * (nc + nf)                              # points per range: 4 ranges per fine pass
+    monkeypatch.setattr(autograd, "_max_points_per_chunk", lambda pf: per_range)
+    results = []
+    for budget_ranges in (4, 0, 2):
+        monkeypatch.setattr(autograd, "SAVE_FINE_BYTES", lib_acts * per_range * budget_ranges)
+        monkeypatch.setattr(autograd, "SAVE_COARSE_BYTES", 1 << 40 if budget_ranges == 4 else 0)
+        for p in m.parameters():
+            p.grad = None
+        if film is not None:
+            film.grad = None
+        out = render_core.render_rays(rays, near, far, m, m, nc, nf, t_rand=tr, film=film)
+        (out[3].square().mean() + out[0].mean() + out[5].mean()).backward()
+        results.append([p.grad.clone() for p in m.parameters()] + ([] if film is None else [film.grad.clone()]))
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert torch.equal(a, b)
