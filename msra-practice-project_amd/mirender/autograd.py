@@ -56,11 +56,21 @@ def _chunk_ranges(pf: fields.PackedField, n: int, s: int, film):
     """The pass split into ray ranges whose saved activations + gradients fit CHUNK_BYTES (whole FiLM groups per
     range).  Forward and backward use the same split, so a range saved in the forward is found again."""
     f_all, groups, rpg = _groups(pf, film, n)
-    if f_all is not None:
-        step = max(1, _max_points_per_chunk(pf) // (rpg * s)) * rpg
-    else:
-        step = max(1, _max_points_per_chunk(pf) // s)
-    return f_all, rpg, [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
+    max_rays = max(1, _max_points_per_chunk(pf) // s)
+    if f_all is None or max_rays >= rpg:
+        step = max_rays if f_all is None else (max_rays // rpg) * rpg          # whole FiLM groups per range
+        return f_all, rpg, [(r0, min(n, r0 + step)) for r0 in range(0, n, step)]
+    # one image alone exceeds the budget (e.g. 256x256 at 72 samples): equal parts of one group per range
+    parts = -(-rpg // max_rays)
+    step = -(-rpg // parts)
+    return f_all, rpg, [(g * rpg + a, g * rpg + min(rpg, a + step)) for g in range(groups) for a in range(0, rpg, step)]
+
+
+def _film_of_range(f_all, rpg, r0, r1):
+    """FiLM rows of the range: its whole groups, or the one group it is a part of."""
+    if f_all is None:
+        return None
+    return f_all[r0 // rpg:max(r0 // rpg + 1, r1 // rpg)]
 
 
 def _save_budget(dev, cap: int) -> int:
@@ -85,14 +95,17 @@ def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothin
         need = per_point * (r1 - r0) * s
         if need > budget:
             break
-        f_c = None if f_all is None else f_all[r0 // rpg:r1 // rpg]
-        raw_k, saved[k] = _forward_saving(pf, rays[r0:r1], z[r0:r1], f_c)
+        raw_k, saved[k] = _forward_saving(pf, rays[r0:r1], z[r0:r1], _film_of_range(f_all, rpg, r0, r1))
         parts.append(raw_k)
         budget -= need
         r_done = r1
     if r_done < n:
-        f_c = None if f_all is None else f_all[r_done // rpg:]
-        parts.append(ops.field_eval_rays(pf, rays[r_done:], z[r_done:], f_c))
+        if r_done % rpg:                                   # finish the image the kept ranges stopped inside
+            r_next = (r_done // rpg + 1) * rpg
+            parts.append(ops.field_eval_rays(pf, rays[r_done:r_next], z[r_done:r_next], _film_of_range(f_all, rpg, r_done, r_next)))
+            r_done = r_next
+        if r_done < n:
+            parts.append(ops.field_eval_rays(pf, rays[r_done:], z[r_done:], None if f_all is None else f_all[r_done // rpg:]))
     return (parts[0] if len(parts) == 1 else torch.cat(parts)), saved
 
 
@@ -115,9 +128,14 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
         f_c = g_c = fp = None
         ng, ppg = 1, pts
         if f_all is not None:
-            ng = (r1 - r0) // rpg
-            ppg = rpg * s
-            f_c, g_c = f_all[r0 // rpg:r0 // rpg + ng], g_film[r0 // rpg:r0 // rpg + ng]
+            f_c = _film_of_range(f_all, rpg, r0, r1)
+            ng = f_c.shape[0]
+            ppg = pts // ng                                   # whole groups, or this part of one group
+            g0 = r0 // rpg
+            part_of_group = (r1 - r0) < rpg
+            # a part of an image adds to that image's row; the first part (and whole groups) overwrite
+            add_to_row = part_of_group and r0 % rpg != 0
+            g_c = torch.empty_like(f_c) if add_to_row else g_film[g0:g0 + ng]
             fp = torch.empty(lib.mi_field_film_partial_floats(ng, ppg), dtype=torch.float32, device=dev)
         if k in saved:
             acts_c, raw_c = saved.pop(k), raw[r0:r1]
@@ -134,6 +152,8 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
                                              _lib.ptr(raw_c), _lib.ptr(g_raw[r0:r1]), ng, ppg, _lib.ptr(part),
                                              _lib.ptr(fp), arr, par, len(out), _lib.ptr(g_c), stream), "mi_field_backward")
         del acts_c
+        if f_all is not None and add_to_row:
+            g_film[g0:g0 + 1] += g_c
         if total is None:
             total = out
         else:

@@ -291,3 +291,15 @@ def test_partial_save_and_recompute_give_the_same_gradients(kind, monkeypatch):
     for other in results[1:]:
         for a, b in zip(results[0], other):
             assert torch.equal(a, b)
+    # ranges smaller than one FiLM image (an image split into parts): same gradients up to the order of the sums
+    monkeypatch.setattr(autograd, "_max_points_per_chunk", lambda pf: 40 * (nc + nf))
+    monkeypatch.setattr(autograd, "SAVE_FINE_BYTES", lib_acts * 32 * (nc + nf) * 5)       # keeps 5 of the 12 parts
+    for p in m.parameters():
+        p.grad = None
+    if film is not None:
+        film.grad = None
+    out = render_core.render_rays(rays, near, far, m, m, nc, nf, t_rand=tr, film=film)
+    (out[3].square().mean() + out[0].mean() + out[5].mean()).backward()
+    split = [p.grad.clone() for p in m.parameters()] + ([] if film is None else [film.grad.clone()])
+    for a, b in zip(results[0], split):
+        assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(a.abs().max()))
