@@ -91,9 +91,11 @@ int mi_gen_rays(int width, int height, double focal, const float* c2w_host, int6
  * z_lin  [Nc] optional table = linspace(near,far,Nc) (pass torch.linspace's CPU output for
  *        bit parity with the CPU reference; NULL = ATen's scalar formula computed in-kernel)
  * t_rand [n,Nc] device pointer, or NULL to draw U[0,1) from Philox4x32-10 keyed by
- *        (seed, ray index, sample index).  out z [n,Nc]. */
+ *        (seed, ray0 + ray index, sample index): ray0 = the index of this call's first ray in the
+ *        caller's larger ray list, so a frame's jitter does not depend on how it is split over calls
+ *        or GPUs.  out z [n,Nc]. */
 int mi_sample_coarse(int64_t n, float near_, float far_, int n_coarse, const float* z_lin,
-                     const float* t_rand, uint64_t seed, float* z, void* stream);
+                     const float* t_rand, uint64_t seed, uint64_t ray0, float* z, void* stream);
 
 /* raw_to_outputs (nerf/render.py:78-103).  raw [n,S,4], z [n,S], rays [n,2,3] (direction
  * used for |d|).  out rgb [n,3], depth [n], acc [n], weights [n,S] (weights may be NULL). */
@@ -118,13 +120,14 @@ int mi_sample_pdf(int64_t n, int n_bins, int n_samples, const float* bins, const
 /* render_rays (nerf/render.py:106-147) for known field kinds, all stages on `stream`.
  *   rays [n,2,3]; n = n_groups*rays_per_group; film tables as in mi_field_eval_rays
  *   outs: rgb_c[n,3] depth_c[n] acc_c[n] rgb_f[n,3] depth_f[n] acc_f[n]
+ *   seed, ray0: as in mi_sample_coarse (used when t_rand is NULL)
  *   workspace: mi_render_workspace_bytes(n, Nc, Nf) bytes */
 int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine);
 int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, const float* packed_fine,
                    const float* film, const float* rays, int64_t n_groups, int64_t rays_per_group,
                    float near_, float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin,
-                   const float* t_rand, uint64_t seed, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f, float* depth_f, float* acc_f,
-                   void* workspace, void* stream);
+                   const float* t_rand, uint64_t seed, uint64_t ray0, float* rgb_c, float* depth_c, float* acc_c,
+                   float* rgb_f, float* depth_f, float* acc_f, void* workspace, void* stream);
 
 /* ---- training: what autograd does for the reference (train_nerf.py:151-168) ------------------ */
 

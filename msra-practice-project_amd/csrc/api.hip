@@ -112,9 +112,9 @@ int mi_gen_rays(int width, int height, double focal, const float* c2w_host, int6
 }
 
 int mi_sample_coarse(int64_t n, float near_, float far_, int n_coarse, const float* z_lin, const float* t_rand,
-                     uint64_t seed, float* z, void* stream) {
+                     uint64_t seed, uint64_t ray0, float* z, void* stream) {
     if (n < 0 || n_coarse < 1 || !z) { set_error("mi_sample_coarse: bad arguments"); return MI_EINVAL; }
-    return launch_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, z, (hipStream_t)stream);
+    return launch_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, ray0, z, (hipStream_t)stream);
 }
 
 int mi_composite(int64_t n, int n_samples, const float* raw, const float* z, const float* rays, float* rgb,
@@ -159,8 +159,8 @@ int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine) {
 int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, const float* packed_fine,
                    const float* film, const float* rays, int64_t n_groups, int64_t rays_per_group, float near_,
                    float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin, const float* t_rand,
-                   uint64_t seed, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f, float* depth_f,
-                   float* acc_f, void* workspace, void* stream) {
+                   uint64_t seed, uint64_t ray0, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f,
+                   float* depth_f, float* acc_f, void* workspace, void* stream) {
     if (!workspace || !rays || !rgb_c || !depth_c || !acc_c || !rgb_f || !depth_f || !acc_f) {
         set_error("mi_render_rays: null pointer argument");
         return MI_EINVAL;
@@ -175,7 +175,7 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
     float* z_f = take(n * (int64_t)S);
     float* raw_f = take(n * (int64_t)S * 4);
     int rc;
-    if ((rc = mi_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, z_c, stream))) return rc;
+    if ((rc = mi_sample_coarse(n, near_, far_, n_coarse, z_lin, t_rand, seed, ray0, z_c, stream))) return rc;
     hipStream_t hs = (hipStream_t)stream;
     if (g_mlp_ev[0]) (void)hipEventRecord(g_mlp_ev[0], hs);
     if ((rc = mi_field_eval_rays(kind_coarse, packed_coarse, film, rays, z_c, n_groups, rays_per_group, n_coarse, raw_c,

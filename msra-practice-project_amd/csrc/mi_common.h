@@ -62,7 +62,7 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
 int launch_gen_rays(int width, int height, double focal, const float* c2w, int64_t ray0, int64_t n, float* rays,
                     int compute_f64, hipStream_t stream);
 int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float* z_lin, const float* t_rand,
-                         uint64_t seed, float* z, hipStream_t stream);
+                         uint64_t seed, uint64_t ray0, float* z, hipStream_t stream);
 int launch_composite(int64_t n, int S, const float* raw, const float* z, const float* rays, float* rgb, float* depth,
                      float* acc, float* weights, hipStream_t stream);
 int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,

@@ -71,7 +71,8 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t ray, uint
 }
 
 __global__ void sample_coarse_kernel(int64_t n, float near_, float far_, int nc, const float* __restrict__ z_lin,
-                                     const float* __restrict__ t_rand, uint64_t seed, float* __restrict__ z) {
+                                     const float* __restrict__ t_rand, uint64_t seed, uint64_t ray0,
+                                     float* __restrict__ z) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * nc) return;
     const int k = (int)(t % nc);
@@ -80,7 +81,7 @@ __global__ void sample_coarse_kernel(int64_t n, float near_, float far_, int nc,
     const float zk = lin(k);
     const float lower = k == 0 ? zk : 0.5f * (zk + lin(k - 1));
     const float upper = k == nc - 1 ? zk : 0.5f * (lin(k + 1) + zk);
-    const float u = t_rand ? t_rand[t] : (float)(philox_u32(seed, (uint64_t)ray, (uint32_t)k) >> 8) * 0x1p-24f;
+    const float u = t_rand ? t_rand[t] : (float)(philox_u32(seed, ray0 + (uint64_t)ray, (uint32_t)k) >> 8) * 0x1p-24f;
     z[t] = lower + (upper - lower) * u;
 }
 
@@ -380,11 +381,11 @@ int launch_gen_rays(int width, int height, double focal, const float* c2w, int64
 }
 
 int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float* z_lin, const float* t_rand,
-                         uint64_t seed, float* z, hipStream_t stream) {
+                         uint64_t seed, uint64_t ray0, float* z, hipStream_t stream) {
     if (n <= 0) return 0;
     const int64_t total = n * nc;
     hipLaunchKernelGGL(sample_coarse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, near_,
-                       far_, nc, z_lin, t_rand, seed, z);
+                       far_, nc, z_lin, t_rand, seed, ray0, z);
     return check_launch("sample_coarse");
 }
 

@@ -34,7 +34,7 @@ SIGNATURES = {
     "mi_field_eval_points": (_int, [_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mi_field_eval_rays": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "mi_gen_rays": (_int, [_int, _int, _f64, ctypes.POINTER(_f32), _i64, _i64, _vp, _int, _vp]),
-    "mi_sample_coarse": (_int, [_i64, _f32, _f32, _int, _vp, _vp, _u64, _vp, _vp]),
+    "mi_sample_coarse": (_int, [_i64, _f32, _f32, _int, _vp, _vp, _u64, _u64, _vp, _vp]),
     "mi_composite": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sample_fine": (_int, [_i64, _f32, _f32, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sample_pdf": (_int, [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
@@ -46,7 +46,7 @@ SIGNATURES = {
     "mi_ray_bank": (_int, [_int, _int, _f32, _vp, _vp, _int, _i64, _vp, _vp]),
     "mi_render_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
-                              _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                              _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_composite_bwd": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_field_packed_bwd_floats": (_i64, [_int]),
     "mi_field_pack_bwd": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),

@@ -177,10 +177,10 @@ def _composite_bwd(raw, z, rays, g_rgb, g_depth, g_acc):
 
 class _RenderRaysFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed, *params):
+    def forward(ctx, pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed, ray0, *params):
         dev = pf_c.device
         n = rays.shape[0]
-        z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed)
+        z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed, ray0=ray0)
         # the coarse pass often gets no gradient at all (pi_GAN trains through rgb_fine only): keep its layer inputs
         # only when they are small; the fine pass may keep as many ranges as half the free HBM holds
         raw_c, ctx.acts_c = _forward_pass(pf_c, rays, z_c, film, SAVE_COARSE_BYTES, all_or_nothing=True)
@@ -221,11 +221,11 @@ class _RenderRaysFn(torch.autograd.Function):
             parts = [g for g in (gfilm_c, gfilm_f) if g is not None]
             if parts:
                 g_film = (parts[0] if len(parts) == 1 else parts[0] + parts[1]).reshape(ctx.film.shape)
-        return (None,) * 7 + (g_film, None, None) + param_grads
+        return (None,) * 7 + (g_film, None, None, None) + param_grads
 
 
-def render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed):
+def render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed, ray0=0):
     """render_rays with gradients to the field parameters and the FiLM table (6-tuple like render.py:147)."""
     params = list(pf_c.params) if pf_c is pf_f else list(pf_c.params) + list(pf_f.params)
     return _RenderRaysFn.apply(pf_c, pf_f, rays.detach(), float(near), float(far), int(nc), int(nf), film,
-                               None if t_rand is None else t_rand.detach(), int(seed), *params)
+                               None if t_rand is None else t_rand.detach(), int(seed), int(ray0), *params)

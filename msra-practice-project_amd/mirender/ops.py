@@ -50,9 +50,10 @@ def gen_rays(width: int, height: int, focal, c2w, device, ray0: int = 0, n: int 
 
 
 def sample_coarse(n: int, near: float, far: float, n_coarse: int, device, t_rand=None, seed: int = 0,
-                  exact_linspace: bool = True) -> torch.Tensor:
+                  exact_linspace: bool = True, ray0: int = 0) -> torch.Tensor:
     """Stratified depths z[n,Nc] (render.py:123-132).  t_rand[n,Nc] injects the jitter; otherwise an
-    in-kernel Philox stream keyed by ``seed`` is used."""
+    in-kernel Philox stream keyed by (``seed``, ``ray0`` + ray index, sample) is used, ``ray0`` being the index of
+    the first ray in the caller's full ray list (so the jitter of a frame does not depend on how it is split)."""
     lib = _lib.load()
     z = torch.empty((n, n_coarse), dtype=torch.float32, device=device)
     if t_rand is not None:
@@ -62,7 +63,7 @@ def sample_coarse(n: int, near: float, far: float, n_coarse: int, device, t_rand
     zl = linspace_table(near, far, n_coarse, device) if exact_linspace else None
     with torch.cuda.device(device):
         _lib.check(lib.mi_sample_coarse(n, float(near), float(far), n_coarse, _lib.ptr(zl), _lib.ptr(t_rand),
-                                        int(seed) & (2 ** 64 - 1), _lib.ptr(z), _lib.stream_ptr(device)),
+                                        int(seed) & (2 ** 64 - 1), int(ray0), _lib.ptr(z), _lib.stream_ptr(device)),
                    "mi_sample_coarse")
     return z
 
@@ -161,7 +162,8 @@ class _Workspace:
 
 
 def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, near: float, far: float,
-                      n_coarse: int, n_fine: int, film=None, t_rand=None, seed: int = 0, exact_linspace: bool = True):
+                      n_coarse: int, n_fine: int, film=None, t_rand=None, seed: int = 0, exact_linspace: bool = True,
+                      ray0: int = 0):
     """render_rays (render.py:106-147) as one C-ABI call: six launches on the current stream.
     Returns the reference's 6-tuple."""
     lib = _lib.load()
@@ -181,6 +183,6 @@ def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, 
         _lib.check(lib.mi_render_rays(pf_c.kind, _lib.ptr(pf_c.refresh()), pf_f.kind, _lib.ptr(pf_f.refresh()),
                                       _lib.ptr(film), _lib.ptr(rays), groups, rpg, float(near), float(far),
                                       n_coarse, n_fine, _lib.ptr(zl), _lib.ptr(ul), _lib.ptr(t_rand),
-                                      int(seed) & (2 ** 64 - 1), *[_lib.ptr(o) for o in outs], _lib.ptr(ws),
+                                      int(seed) & (2 ** 64 - 1), int(ray0), *[_lib.ptr(o) for o in outs], _lib.ptr(ws),
                                       _lib.stream_ptr(dev)), "mi_render_rays")
     return tuple(outs)

@@ -89,8 +89,10 @@ def _generic_field(network, rays, z, chunk=1024 * 64):
 
 
 def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fine_sample_num, *,
-                t_rand=None, seed=None, film=None):
+                t_rand=None, seed=None, film=None, ray0=0):
     """nerf/render.py:106-147.  rays [N,2,3] -> (rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f).
+    `ray0`: index of rays[0] in the caller's full ray list; the seeded jitter is keyed by (seed, ray0 + k, sample),
+    so a frame rendered in pieces (chunks, GPUs) gets the jitter it would get in one call.
     `film` [b,9,512] (FiLM fields only) renders b images in one call: rays are b equal consecutive groups and
     group g uses film[g]; by default the model's own film_params (one image) are used like the reference."""
     dev = _device_of(coarse_model, fine_model, rays=rays)
@@ -109,12 +111,12 @@ def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fi
             film = None
         if needs_grad:
             from . import autograd
-            return autograd.render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0)
-        return ops.render_rays_fused(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0)
+            return autograd.render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0, ray0)
+        return ops.render_rays_fused(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0, ray0=ray0)
 
     # generic path: sampling / compositing kernels around an arbitrary callable
     n = rays.shape[0]
-    z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed or 0)
+    z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed or 0, ray0=ray0)
     raw_c = ops.field_eval_rays(pf_c, rays, z_c) if pf_c is not None and not fields.is_film(pf_c.kind) \
         else _generic_field(coarse_model, rays, z_c)
     rgb_c, depth_c, acc_c, w_c = ops.composite(raw_c, z_c, rays)
@@ -140,8 +142,7 @@ def _render_image_device(width, height, focal, pose, near, far, coarse_model, fi
         m = min(step, ray0 + n_rays - i)
         rays = ops.gen_rays(width, height, focal, pose, dev, i, m)
         tr = None if t_rand is None else t_rand[i - ray0:i - ray0 + m]   # row k of t_rand <-> ray ray0 + k
-        out = render_rays(rays, near, far, coarse_model, fine_model, nc, nf, t_rand=tr,
-                          seed=None if seed is None else seed + i)
+        out = render_rays(rays, near, far, coarse_model, fine_model, nc, nf, t_rand=tr, seed=seed, ray0=i)
         parts.append(out[3:6])
     if len(parts) == 1:
         return parts[0]

@@ -109,6 +109,9 @@ def test_sample_coarse_philox(mi):
     assert float(u.min()) >= 0.0 and float(u.max()) < 1.0 + 1e-6
     assert abs(float(u.mean()) - 0.5) < 5e-3 and abs(float(u.var()) - 1 / 12) < 5e-3
     assert bool((a[:, 1:] >= a[:, :-1]).all())
+    # the stream is keyed by the absolute ray index: a call that starts at ray 1000 of the list reproduces its rows
+    tail = mi.ops.sample_coarse(n - 1000, 2.0, 6.0, nc, dev(), None, seed=7, ray0=1000)
+    assert torch.equal(tail, a[1000:])
 
 
 # ------------------------------------------------------------------ compositing
