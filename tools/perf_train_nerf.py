@@ -1,0 +1,23 @@
+"""Micro-benchmark (GPU box): one NeRF training step at 8192 rays, for kernel-level profiles (rocprofv3 --kernel-trace)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "msra-practice-project_amd")]
+import torch
+from mirender import fields, render_core, train
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+cm, fm = fields.NeRF().to(dev), fields.NeRF().to(dev)
+n = 8192
+rays = torch.randn(n, 2, 3, device=dev); rays[:, 0] = torch.tensor([0., 0., 4.], device=dev); rays[:, 1, 2] = -1
+tgt = torch.rand(n, 4, device=dev)
+params = list(cm.parameters()) + list(fm.parameters())
+def step():
+    out = render_core.render_rays(rays, 2.0, 6.0, cm, fm, 64, 128)
+    loss, _ = train.nerf_loss(out, tgt[:, :3], tgt[:, 3], use_alpha=True)
+    for p in params: p.grad = None
+    loss.backward()
+for _ in range(2): step()
+torch.cuda.synchronize(); t = time.time(); k = 6
+for _ in range(k): step()
+torch.cuda.synchronize(); dt = (time.time() - t) / k
+print(f"nerf train n={n}: {dt*1e3:.2f} ms/step", flush=True)
