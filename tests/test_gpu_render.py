@@ -343,3 +343,38 @@ def test_concurrent_threads_on_their_own_streams(nerf_render):
     for a, b in zip(out, serial):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n,nc,nf", [(1, 8, 8), (2, 3, 1), (5, 3, 0), (33, 256, 256), (130, 1, 4)])
+def test_render_rays_edge_shapes(nerf_render, n, nc, nf):
+    """Edge shapes of render_rays (render.py:106-147): a single ray (the reference's squeeze at :120-121 collapses
+    there; the evident intent is one ray), the smallest sample counts sample_pdf accepts (Nc=3), Nf in {0, 1}, 512
+    samples per ray.  Coarse outputs against the oracle at 1e-4; the fine pass with the oracle's depths injected."""
+    from mirender import fields, ops, render_core
+    sd_c = synth.state_dict("nerf", seed=5, sharp=True, bias_jitter=0.05)
+    sd_f = synth.state_dict("nerf", seed=6, sharp=True, bias_jitter=0.05)
+    cm, fm = model("nerf", sd_c), model("nerf", sd_f)
+    rays = R.rays_from_camera(40, 40, 55.5, synth.pose_degrees(4.0, -35.0, -30.0))[700:700 + n]
+    tr = synth.t_rand(n, nc, seed=9)
+    if nc < 3:
+        with pytest.raises(Exception):                      # sample_pdf needs >= 2 bins = 3 coarse samples
+            render_core.render_rays(torch.from_numpy(rays).to(dev()), 2.0, 6.0, cm, fm, nc, nf, t_rand=tr.to(dev()))
+        return
+    with torch.no_grad():
+        rr = torch.from_numpy(rays) if n > 1 else torch.from_numpy(np.concatenate([rays, rays]))   # oracle: N >= 2
+        tt = tr if n > 1 else torch.cat([tr, tr])
+        ref = R.render_rays(rr, 2.0, 6.0, ofields.make_field("nerf", sd_c), ofields.make_field("nerf", sd_f), nc, nf, tt)
+        got = render_core.render_rays(torch.from_numpy(rays).to(dev()), 2.0, 6.0, cm, fm, nc, nf, t_rand=tr.to(dev()))
+    assert [tuple(g.shape) for g in got] == [(n, 3), (n,), (n,)] * 2
+    assert stats(got[0], ref.rgb_c[:n])[0] <= TOL and stats(got[2], ref.acc_c[:n])[0] <= TOL
+    assert stats(got[1], ref.depth_c[:n])[0] <= 5 * TOL
+    assert all(bool(torch.isfinite(g).all()) for g in got)
+    rd = torch.from_numpy(rays).to(dev())
+    zf = ref.z_fine[:n].to(dev())
+    raw = ops.field_eval_rays(fields.as_packed_field(fm), rd, zf)
+    rgb, depth, acc, _ = ops.composite(raw, zf, rd)
+    ff64 = ofields.make_field("nerf", {k: v.double() for k, v in sd_f.items()})
+    with torch.no_grad():
+        i64 = R.render_rays_f64(rr, 2.0, 6.0, ff64, ff64, nc, nf, tt, ref.z_fine)
+    floor = 4 * max(stats(i64.rgb_f, ref.rgb_f)[0], stats(i64.acc_f, ref.acc_f)[0])
+    assert stats(rgb, ref.rgb_f[:n])[0] <= max(TOL, floor) and stats(acc, ref.acc_f[:n])[0] <= max(TOL, floor)
