@@ -378,6 +378,55 @@ __device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
         }
 }
 
+// One FiLM chain layer (bwd_layer's EPI_FILM case) whose dL/du rows do not burst out of the last row either: FiLM
+// layers carry gamma (.) dL/du in X, so X cannot be stored later as dA can; instead the epilogue parks each dL/du
+// quarter in the register that held its C quarter (`ring`, owned by the kernel), and the NEXT layer's mid slot
+// 2(j%8) of K block j/8 stores it right before loading its own C quarter into the same register.
+//   STORE_PREV: ring holds the previous layer's dL/du (-> prev_dU);  KEEP: leave this layer's dL/du in ring
+//   (the caller's next layer stores it) instead of storing it from the epilogue.
+template <int NEXT_BLOCK, bool SCALED, bool FILM_NEXT, bool STORE_PREV, bool KEEP, class BSel>
+__device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSel bsel, f32x16 (&acc)[8], f32x16 (&X)[8],
+                                                 f32x4 (&ring)[32], const float* __restrict__ C_rows,
+                                                 float* __restrict__ dU, float* __restrict__ prev_dU, int64_t p,
+                                                 bool valid, int issue_slot, int next_film_layer, const float* film_row) {
+    const int h = c.h;
+    const lds4_t pv = lds_base(c.smem + kLdsAux0 + h * 16);          // aux slot 0 (the sigma head's row for SCALED)
+    const lds4_t pg = lds_base(film_row + h * 4);
+    const f32x4* srow = reinterpret_cast<const f32x4*>(C_rows + p * 256 + 4 * h);
+    f32x4* drow = reinterpret_cast<f32x4*>(dU + p * 256 + 4 * h);
+    f32x4* prow = reinterpret_cast<f32x4*>(prev_dU + p * 256 + 4 * h);
+    const auto pre = [&](auto mc, auto pc) {
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
+        if constexpr (SCALED) {
+            const f32x4 w = pv[piece * 64 + m * 8 + rg];
+            acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
+        } else {
+            acc[m][4 * rg + 0] = 0.f; acc[m][4 * rg + 1] = 0.f; acc[m][4 * rg + 2] = 0.f; acc[m][4 * rg + 3] = 0.f;
+        }
+    };
+    const auto mid = [&](auto kbc, auto sc) {
+        constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
+        if constexpr (kb < 4 && slot < 16 && (slot & 1) == 0) {
+            constexpr int idx = (j / 4) * 8 + (j % 4) * 2;
+            if constexpr (STORE_PREV) { if (valid) prow[idx] = ring[j]; }
+            ring[j] = srow[idx];
+        }
+    };
+    const auto post = [&](auto mc, auto pc) {
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value, j = m * 4 + rg;
+        const f32x4 g = pg[m * 8 + rg * 2];
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o[q] = ring[j][q] * acc[m][4 * rg + q];
+            X[m][4 * rg + q] = o[q] * g[q];
+        }
+        if constexpr (KEEP) ring[j] = o;
+        else { if (valid) drow[m * 8 + rg * 2] = o; }
+    };
+    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true>(c, issue_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
+}
+
 template <bool USE_DIR>
 __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -421,14 +470,15 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     film_bwd_store<8>(acc, X, C(8), film_row(0), dU(8), p, valid, c.h);                          // hidden_layer_rgb
     // Chain layer j computes dX_j = W_{j+1}^T dA_{j+1}; its epilogue uses C_j and FiLM row j (film slot (8-j)&1) and
     // it DMAs FiLM row j-1 into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
-    bwd_layer<8, 8, 0, 32, EPI_FILM, true, true>(c, 0, 3, ds, sel_x, acc, X, C(7), dU(7), 256, p, valid, 1, 6, film_row(1));
+    f32x4 ring[32];                                            // C quarters on the way in, dL/du quarters on the way out
+    film_chain_layer<32, true, true, false, true>(c, 3, ds, sel_x, acc, X, ring, C(7), dU(7), nullptr, p, valid, 1, 6, film_row(1));
 #pragma unroll 1
     for (int j = 6; j >= 1; --j) {                                                               // hidden_layers[5..0]
         const int fs = (8 - j) & 1;
-        bwd_layer<8, 8, 0, 32, EPI_FILM, false, true>(c, 0, 0, 0.f, sel_x, acc, X, C(j), dU(j), 256, p, valid, fs, j - 1,
+        film_chain_layer<32, false, true, true, true>(c, 0, 0.f, sel_x, acc, X, ring, C(j), dU(j), dU(j + 1), p, valid, fs, j - 1,
                                                       film_row(fs));
     }
-    bwd_layer<8, 8, 0, 0, EPI_FILM, false, false>(c, 0, 0, 0.f, sel_x, acc, X, C(0), dU(0), 256, p, valid, 0, 0, film_row(0));  // input_layer
+    film_chain_layer<0, false, false, true, false>(c, 0, 0.f, sel_x, acc, X, ring, C(0), dU(0), dU(1), p, valid, 0, 0, film_row(0));  // input_layer
 }
 
 // FiLM layer finishing for ONE image (group) g.  T[f][k] = sum_{p in g} dL/du[p][f] X[p][k] (tk = 256, or the 3
