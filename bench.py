@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: rays/s of the ray-march + field-MLP + alpha-composite path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: spawns its own N ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One step = one synthetic 800x800 frame (640 000 rays) rendered with 64 coarse + 128 fine samples per ray
@@ -17,11 +17,16 @@ Extra objects in the line:
                 per launch / mean launch duration, peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md)
   frame64       the "800^2 frame @ 64 samples" figure of BASELINE.json's metric (Nc=64, Nf=0, one model)
   cpu_baseline  the CPU oracle (oracle/render_ref.py, PyTorch CPU, all host cores) on a bounded sample of
-                the same workload, rank 0, N=1 only
+                the same workload, rank 0, N=1 only; with it `psnr_vs_ref`: held-out-view PSNR of a TinyNeRF fitted
+                to a synthetic teacher scene by the HIP path and by the reference loop on the CPU (oracle/fit_ref.py)
+  train         N=1 only: the secondary training workloads (nerf 1024-ray step, pi_GAN C4 step), 3 steps each
+  collective    N>1: ranks seen by torch.distributed, per-rank mean MLP launch time, all-gather time per frame
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -133,7 +138,7 @@ def cpu_baseline(sample_rays=8192):
                       f"NeRF coarse+fine, torch CPU no_grad, {dt:.1f} s"}
 
 
-def train_workload(args, world, rank, dev):
+def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=None):
     """Secondary workloads (not the headline line): one training step per `step`, data-parallel over ranks
     (each rank its own batch = weak scaling) with one flat RCCL all-reduce of the renderer gradients.
       c4          pi_GAN generator step, 128x128, batch 32 per GPU, Nc=12 Nf=24 (BASELINE config C4)
@@ -141,8 +146,11 @@ def train_workload(args, world, rank, dev):
       nerf_train  nerf/train_nerf.py step: 1024 rays per GPU, 64+128 samples, coarse+fine NeRF, Adam"""
     from mirender import dist as mdist, fields, pigan, render_core, train
     torch.manual_seed(rank)
-    if args.workload in ("c4", "c5"):
-        c5 = args.workload == "c5"
+    workload = workload or args.workload
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    if workload in ("c4", "c5"):
+        c5 = workload == "c5"
         # C4: 128x128, batch 32 per GPU, Nc=12 Nf=24, generator step.  C5: 256x256, batch 4 per GPU (global 32 on 8
         # GPUs), Nc=24 Nf=48, one whole training step = the D-step's generator forward (no grad, pi_GAN/train.py:108-111)
         # + the G-step forward/backward (SURVEY.md 8d); the discriminator itself is stock PyTorch and not timed here.
@@ -193,31 +201,80 @@ def train_workload(args, world, rank, dev):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
-        achieved = flops * args.steps / elapsed / 1e12
-        print(json.dumps({
-            "metric": "rays/sec (training step)", "value": world * rays_per_step * args.steps / elapsed, "unit": "rays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step,
-                       "parallelism": f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU"},
-            "roofline": {"bound": "mfma", "kernel": "whole training step (forward, backward chain, dW GEMMs)",
-                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "note": "algorithmic FLOPs = 2 x MACs x (1 per no-grad pass + 3 per trained pass), SURVEY.md 8d"},
-        }), flush=True)
+    achieved = flops * steps / elapsed / 1e12
+    return {
+        "metric": "rays/sec (training step)", "value": world * rays_per_step * steps / elapsed, "unit": "rays/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step,
+                   "parallelism": f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU"},
+        "roofline": {"bound": "mfma", "kernel": "whole training step (forward, backward chain, dW GEMMs)",
+                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "note": "algorithmic FLOPs = 2 x MACs x (1 per no-grad pass + 3 per trained pass), SURVEY.md 8d"},
+    }
+
+
+def psnr_vs_ref(dev):
+    """The metric's "PSNR vs ref" clause on a trained result: a TinyNeRF pair fitted to the synthetic teacher scene of
+    oracle/fit_ref.py (60 Adam steps of 256 rays, 24x24 views, 16+16 samples) by the HIP path and by the reference
+    loop on the CPU - same initial weights, batches and jitter; held-out-view PSNR of both.  Part of the CPU-baseline
+    leg (the only place bench.py touches oracle/)."""
+    from mirender import fields, render_core
+    from oracle import fit_ref, render_ref as R
+    steps, batch = 60, 256
+    scene = fit_ref.Scene()
+    cpu_losses, cpu_psnr, _ = fit_ref.fit_cpu(scene, steps, batch)
+    cm, fm = fields.TinyNeRF().to(dev), fields.TinyNeRF().to(dev)
+    cm.load_state_dict(scene.student_init[0])
+    fm.load_state_dict(scene.student_init[1])
+    opt = torch.optim.Adam(list(cm.parameters()) + list(fm.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    loss = None
+    for step in range(steps):
+        rays, rgb, tr = scene.batch(step, batch)
+        rgb = rgb.to(dev)
+        out = render_core.render_rays(rays.to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf, t_rand=tr.to(dev))
+        loss = torch.mean((out[3] - rgb) ** 2) + torch.mean((out[0] - rgb) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for g in opt.param_groups:
+            g["lr"] = fit_ref.lr_at(step + 1)
+    with torch.no_grad():
+        held = render_core.render_rays(scene.rays[-1].to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf,
+                                       t_rand=scene.heldout_jitter().to(dev))
+    hip_psnr = R.psnr(held[3].cpu().numpy(), scene.images[-1].numpy())
+    return {"hip_db": hip_psnr, "cpu_reference_loop_db": cpu_psnr, "diff_db": hip_psnr - cpu_psnr,
+            "final_loss_hip": float(loss), "final_loss_cpu": cpu_losses[-1],
+            "scene": f"teacher tiny_nerf field, six 24x24 training views + 1 held out, 16+16 samples, {steps} Adam steps "
+                     f"of {batch} rays (nerf/train_nerf.py:124-176 loop), PSNR of the held-out view against the teacher image"}
+
+
+def spawn_command(argv, n_gpus: int, port: int):
+    """The command line `bench.py --gpus N` runs when it is started WITHOUT a torch.distributed.run environment:
+    the same script under torch.distributed.run, one rank per GPU of this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 def main():
@@ -229,20 +286,29 @@ def main():
     ap.add_argument("--no-frame64", action="store_true",
                     help="skip the secondary 64-sample frame (profiling runs: keeps every nerf_fwd_kernel launch in the "
                          "trace one of the timed step's two launches, so rocprofv3's average matches roofline.avg_launch_ms)")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary training workloads folded into the N=1 line")
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5", "nerf_train"],
                     help="c3 (default, the headline line) | c4 | c5 | nerf_train (secondary training workloads)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (importing torch does not initialise
+        # HIP) and never will - it starts N fresh rank processes and relays their exit code; rank 0 prints the line
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(spawn_command(sys.argv[1:], args.gpus, _free_port()), env=env).returncode)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     if args.workload != "c3":
-        train_workload(args, world, rank, dev)
+        line = train_workload(args, world, rank, dev)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -256,9 +322,11 @@ def main():
     n_local = mdist.shard_range(W * H, rank, world)
     n_local = n_local[1] - n_local[0]
 
-    def frame(i, nf=NF, fine_model=fine):
+    gather_events = []
+
+    def frame(i, nf=NF, fine_model=fine, timing=None):
         return mdist.render_image_dist(W, H, focal, poses[i % len(poses)], NEAR, FAR, coarse, fine_model, NC, nf,
-                                       seed=1000 + i)
+                                       seed=1000 + i, timing=timing)
 
     def sync():
         if world > 1:
@@ -272,7 +340,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         timer.arm()
-        out = frame(args.warmup + i)
+        out = frame(args.warmup + i, timing=gather_events)
     timer.disarm()
     sync()
     elapsed = time.perf_counter() - t0
@@ -295,13 +363,15 @@ def main():
     # correction of MI355X_MICROARCH.md, per point) scaled to the mean points per launch.  null if absent.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_nerf_fwd.json")))
+        pmc_name = next(n for n in ("r02_pmc_nerf_fwd.json", "r01_pmc_nerf_fwd.json")
+                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
         traffic = pmc["derived_fine_launch"]["hbm_bytes_per_point_upper"] * mean_flops / flops_pt
-    except (OSError, KeyError, ValueError):
-        pass
+    except (OSError, KeyError, ValueError, StopIteration):
+        pmc_name = None
     roofline = {"bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_nerf_fwd.json)",
+                "traffic_unit": f"HBM bytes per launch (PMC, profiles/{pmc_name})",
                 "launches": len(launch_ms), "avg_launch_ms": mean_ms, "flops_per_launch": mean_flops,
                 "mlp_share_of_step": sum(launch_ms) / (elapsed * 1e3)}
 
@@ -320,6 +390,36 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             f64_s = float(t.item())
 
+    # what the collective cost and who took part: ranks as torch.distributed sees them, every rank's mean MLP launch
+    # time (the shards are equal, so these should be too) and its mean all-gather time per frame
+    collective = None
+    if world > 1:
+        gather_ms = [a.elapsed_time(b) for a, b in gather_events]
+        mine = torch.tensor([mean_ms, sum(gather_ms) / max(1, len(gather_ms))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        collective = {"backend": dist.get_backend(), "n_ranks_seen": dist.get_world_size(),
+                      "per_rank_avg_launch_ms": [float(t[0]) for t in allr],
+                      "per_rank_allgather_ms": [float(t[1]) for t in allr],
+                      "allgather_bytes_per_rank": int(-(-W * H // world) * 5 * 4), "frames": len(gather_ms),
+                      "note": "one all_gather_into_tensor of packed [n_local, 5] fp32 per frame, issued after the last "
+                              "composite kernel (no overlap: the frame is not complete before that)"}
+
+    # N=1 only: the secondary training workloads inside this (driver-timed) run, after the frame's workspace is freed
+    train = None
+    if world == 1 and not args.no_train:
+        del out
+        from mirender import ops
+        ops._Workspace.release()
+        torch.cuda.empty_cache()
+        train = {}
+        for wl in ("nerf_train", "c4"):
+            r = train_workload(args, world, rank, dev, workload=wl, steps=3, warmup=1)
+            train[wl] = {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "tflops": r["roofline"]["achieved"], "frac_of_fp32_mfma_peak": r["roofline"]["frac"],
+                         "workload": r["config"]["workload"]}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         rays_per_s = W * H * args.steps / elapsed
         line = {
@@ -337,9 +437,14 @@ def main():
         if f64_s is not None:
             line["frame64"] = {"ms_per_frame": f64_s * 1e3, "rays_per_s": W * H / f64_s,
                                "workload": "800x800 frame, 64 samples/ray, one NeRF 8x256 (Nf=0)"}
+        if collective is not None:
+            line["collective"] = collective
+        if train is not None:
+            line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = rays_per_s / line["cpu_baseline"]["value"]
+            line["psnr_vs_ref"] = psnr_vs_ref(dev)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

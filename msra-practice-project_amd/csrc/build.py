@@ -54,16 +54,22 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, *COMMON, *extra, "-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd, timeout=1500)
+            jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+    # the translation units are independent (the two MLP files take minutes each): compile them side by side
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, timeout=1800)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1) or 1) as pool:
+        list(pool.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT]
         if verbose:

@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     };
     const auto sin_act = [&](int l) {
         if constexpr (SAVE)
-            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
+            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, smem + kLdsAux0, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
                                          a.save + (int64_t)(8 + 512 * (l - 1) + 256) * SP, 256, pt.p, pt.valid);
         else
-            activate<8, ACT_SIN30>(acc, X, nullptr, c.h);
+            activate<8, ACT_SIN30>(acc, X, nullptr, c.h, smem + kLdsAux0);
     };
     if constexpr (SAVE) {
         if (pt.valid && c.h == 0) {
@@ -315,9 +315,9 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const auto film_act = [&](int l, int slot_) {
         if constexpr (SAVE) {
             float* base = a.save + (int64_t)(8 + 512 * l) * SP;
-            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, base, base + 256 * SP, 256, pt.p, pt.valid);
+            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0, base, base + 256 * SP, 256, pt.p, pt.valid);
         } else {
-            activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h);
+            activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0);
         }
     };
     if constexpr (SAVE) {
@@ -373,9 +373,9 @@ int launch_mlp(int kind, const MlpArgs& a, int64_t n_groups, hipStream_t stream)
     if (blocks > 0x7fffffffLL) { set_error("too many point tiles (%lld)", (long long)blocks); return -1; }
     const dim3 grid((unsigned)blocks), block(256);
     const size_t lds = kLdsFloats * sizeof(float);
-    // 84 KiB of dynamic LDS: raise the per-kernel limit once (host-side attribute, no device work)
-    static bool attr_done = false;
-    if (!attr_done) {
+    // 148 KiB of dynamic LDS: raise the per-kernel limit once per device (host-side attribute, no device work)
+    static PerDeviceOnce attr_once;
+    const int arc = attr_once.run([&]() {
         const void* fns[] = {(const void*)nerf_fwd_kernel<false, false>, (const void*)nerf_fwd_kernel<false, true>,
                              (const void*)nerf_fwd_kernel<true, false>, (const void*)nerf_fwd_kernel<true, true>,
                              (const void*)siren_fwd_kernel<false>, (const void*)siren_fwd_kernel<true>,
@@ -385,8 +385,9 @@ int launch_mlp(int kind, const MlpArgs& a, int64_t n_groups, hipStream_t stream)
             const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -2; }
         }
-        attr_done = true;
-    }
+        return 0;
+    });
+    if (arc) return arc;
     const bool sv = a.save != nullptr;
 #define MI_LAUNCH(K) hipLaunchKernelGGL((K), grid, block, lds, stream, a)
     switch (kind) {

@@ -816,12 +816,13 @@ static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P
     float* tmp = partial + (int64_t)n * rec;                                          // level-1 sums
     if (lda != TM || ldx != TK) { set_error("dw_gemm: rows must be dense (lda %d != %d or ldx %d != %d)", lda, TM, ldx, TK); return -1; }
     constexpr size_t lds = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;                                                   // one per template instance
+    const int arc = attr_once.run([&]() {
         if (hipFuncSetAttribute((const void*)dw_gemm_kernel<CB, WM, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) { set_error("hipFuncSetAttribute(dw_gemm) failed"); return -2; }
-        attr_done = true;
-    }
+        return 0;
+    });
+    if (arc) return arc;
     hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), lds, stream, dA, X, P, slab, partial, gb ? 1 : 0);
     const float* src = partial;
     int m = n;
@@ -912,9 +913,9 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
     const int64_t P = n_groups * points_per_group;
     if (P <= 0) return 0;
     if (kind < 0 || kind > 4) { set_error("unknown field kind %d", kind); return -1; }
-    static bool attr_done = false;
     const size_t lds = kLdsFloats * sizeof(float);
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    const int arc = attr_once.run([&]() {
         const void* fns[] = {(const void*)nerf_bwd_kernel<false>, (const void*)nerf_bwd_kernel<true>,
                              (const void*)siren_bwd_kernel, (const void*)film_bwd_kernel<true>,
                              (const void*)film_bwd_kernel<false>};
@@ -922,8 +923,9 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 set_error("hipFuncSetAttribute failed"); return -2;
             }
-        attr_done = true;
-    }
+        return 0;
+    });
+    if (arc) return arc;
     const int64_t tpg = (points_per_group + 127) / 128;
     BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P, film, film_partial, points_per_group, tpg, n_groups * tpg};
     const unsigned blocks = (unsigned)((kind == 2 || kind == 3) ? n_groups * tpg : (P + 127) / 128);

@@ -183,7 +183,15 @@ __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x
     });
 }
 
-// acc = bias (+ W3 * xyz for the K=3 inputs of Siren/FiLM nets), from the layer's aux slot.
+// Rounding order of a linear layer.  The reference's x W^T + b (torch F.linear on MKL) is an FMA chain over k
+// starting from ZERO with the bias added to the finished sum; measured against fp64, preloading the bias into the
+// accumulator instead (one add less) is 1.8x less accurate for the SIREN-family layers, whose pre-activations
+// (|u| ~ 0.03) are smaller than their biases (|b| <= 0.06): every partial sum then rounds at the bias's ulp.
+// v_mfma_f32_32x32x2_f32 is two chained IEEE FMAs (tools/probes/mfma_rounding.hip), so starting the accumulators
+// at zero (or at the K = 3 products, the first columns of the chain) and adding the bias in the epilogue gives the
+// reference's error, not 1.8x it.
+
+// acc = W3 * xyz for the K = 3 inputs of Siren/FiLM nets (zero otherwise); the bias is added by the epilogue.
 template <int MB, bool K3>
 __device__ __forceinline__ void init_acc(const float* aux, int h, int k3_piece, float x, float y, float z,
                                          f32x16 (&acc)[8]) {
@@ -192,24 +200,26 @@ __device__ __forceinline__ void init_acc(const float* aux, int h, int k3_piece, 
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            f32x4 t = pb[m * 8 + rg];
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
             if constexpr (K3) {
                 const f32x4 w0 = pb[(k3_piece + 0) * 64 + m * 8 + rg];
                 const f32x4 w1 = pb[(k3_piece + 1) * 64 + m * 8 + rg];
                 const f32x4 w2 = pb[(k3_piece + 2) * 64 + m * 8 + rg];
-                t.x = fmaf(w2.x, z, fmaf(w1.x, y, fmaf(w0.x, x, t.x)));
-                t.y = fmaf(w2.y, z, fmaf(w1.y, y, fmaf(w0.y, x, t.y)));
-                t.z = fmaf(w2.z, z, fmaf(w1.z, y, fmaf(w0.z, x, t.z)));
-                t.w = fmaf(w2.w, z, fmaf(w1.w, y, fmaf(w0.w, x, t.w)));
+                t.x = fmaf(w2.x, z, fmaf(w1.x, y, w0.x * x));
+                t.y = fmaf(w2.y, z, fmaf(w1.y, y, w0.y * x));
+                t.z = fmaf(w2.z, z, fmaf(w1.z, y, w0.z * x));
+                t.w = fmaf(w2.w, z, fmaf(w1.w, y, w0.w * x));
             }
             acc[m][4 * rg + 0] = t.x; acc[m][4 * rg + 1] = t.y; acc[m][4 * rg + 2] = t.z; acc[m][4 * rg + 3] = t.w;
         }
     }
 }
 
-// Activation epilogue: X = act(acc).  FiLM reads gamma|beta of this layer from the film slot.
+// Activation epilogue: X = act(acc + bias).  FiLM reads gamma|beta of this layer from the film slot.
 template <int MB, int ACT>
-__device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h) {
+__device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
+                                         const float* aux) {
+    const lds4_t pb = lds_base(aux + h * 16);
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);   // gamma at f, beta at 256 + f
 #pragma unroll
@@ -217,13 +227,14 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             f32x4 g, b;
+            const f32x4 bias = pb[m * 8 + rg];
             if constexpr (ACT == ACT_FILM) {
                 g = pf[m * 8 + rg * 2];
                 b = pf[64 + m * 8 + rg * 2];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = acc[m][4 * rg + q];
+                const float v = __fadd_rn(acc[m][4 * rg + q], bias[q]);
                 float o;
                 if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
                 else if constexpr (ACT == ACT_SIN30) o = hw_sin30(v);
@@ -239,8 +250,10 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
 // the derivative factor C = 30 cos(30 u).
 template <int MB, int ACT>
 __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
-                                               float* __restrict__ x_rows, float* __restrict__ c_rows, int64_t ld, int64_t p, bool valid) {
+                                               const float* aux, float* __restrict__ x_rows, float* __restrict__ c_rows,
+                                               int64_t ld, int64_t p, bool valid) {
     static_assert(ACT == ACT_SIN30 || ACT == ACT_FILM, "sin activations only");
+    const lds4_t pb = lds_base(aux + h * 16);
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
     f32x4* xrow = reinterpret_cast<f32x4*>(x_rows + p * ld + 4 * h);
@@ -250,13 +263,14 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             f32x4 g, b, xo, co;
+            const f32x4 bias = pb[m * 8 + rg];
             if constexpr (ACT == ACT_FILM) {
                 g = pf[m * 8 + rg * 2];
                 b = pf[64 + m * 8 + rg * 2];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float v = acc[m][4 * rg + q];
+                const float v = __fadd_rn(acc[m][4 * rg + q], bias[q]);
                 float u = v;
                 if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), b[q]);
                 const SinCos sc = hw_sincos30(u);
@@ -331,30 +345,47 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     const lds4_t pb = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
+    f32x4 bias_q[2], g_q[2], bb_q[2];
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
-        f32x4 t = pb[m * 8 + rg];
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};              // the chain starts at zero; post adds the bias (see init_acc)
         if constexpr (K3) {
             const f32x4 w0 = pb[(k3_piece + 0) * 64 + m * 8 + rg];
             const f32x4 w1 = pb[(k3_piece + 1) * 64 + m * 8 + rg];
             const f32x4 w2 = pb[(k3_piece + 2) * 64 + m * 8 + rg];
-            t.x = fmaf(w2.x, z, fmaf(w1.x, y, fmaf(w0.x, x, t.x)));
-            t.y = fmaf(w2.y, z, fmaf(w1.y, y, fmaf(w0.y, x, t.y)));
-            t.z = fmaf(w2.z, z, fmaf(w1.z, y, fmaf(w0.z, x, t.z)));
-            t.w = fmaf(w2.w, z, fmaf(w1.w, y, fmaf(w0.w, x, t.w)));
+            t.x = fmaf(w2.x, z, fmaf(w1.x, y, w0.x * x));
+            t.y = fmaf(w2.y, z, fmaf(w1.y, y, w0.y * x));
+            t.z = fmaf(w2.z, z, fmaf(w1.z, y, w0.z * x));
+            t.w = fmaf(w2.w, z, fmaf(w1.w, y, w0.w * x));
         }
         acc[m][4 * rg + 0] = t.x; acc[m][4 * rg + 1] = t.y; acc[m][4 * rg + 2] = t.z; acc[m][4 * rg + 3] = t.w;
+        if constexpr (m == 0 && rg == 0) {           // first hook after the layer's first barrier: the aux slot has landed
+            bias_q[0] = pb[0];
+            if constexpr (ACT == ACT_FILM) { g_q[0] = pf[0]; bb_q[0] = pf[64]; }
+        }
     };
+    // The epilogue's LDS operands (bias, FiLM gamma|beta) are read ONE HOOK AHEAD into a two-deep register queue: a
+    // ds_read consumed in the hook that issues it puts its whole round trip (~100 cycles > one MFMA's 64) on the
+    // wave's in-order issue path, between two MFMAs.
     const auto post = [&](auto mc, auto pc) {
-        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
+        constexpr int m = decltype(mc)::value, rg = decltype(pc)::value, idx = m * 4 + rg;
         f32x4 g, bb, xo, co;
+        const f32x4 bias = bias_q[idx & 1];
         if constexpr (ACT == ACT_FILM) {
-            g = pf[m * 8 + rg * 2];
-            bb = pf[64 + m * 8 + rg * 2];
+            g = g_q[idx & 1];
+            bb = bb_q[idx & 1];
+        }
+        if constexpr (idx + 1 < MB * 4) {
+            constexpr int m1 = (idx + 1) / 4, rg1 = (idx + 1) % 4;
+            bias_q[(idx + 1) & 1] = pb[m1 * 8 + rg1];
+            if constexpr (ACT == ACT_FILM) {
+                g_q[(idx + 1) & 1] = pf[m1 * 8 + rg1 * 2];
+                bb_q[(idx + 1) & 1] = pf[64 + m1 * 8 + rg1 * 2];
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float v = acc[m][4 * rg + q];
+            const float v = __fadd_rn(acc[m][4 * rg + q], bias[q]);
             float o;
             if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
             else if constexpr (ACT == ACT_LINEAR) o = v;
@@ -425,14 +456,12 @@ __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + expf(-v
 // c < 3 -> sin(2^i x_c), else cos(2^i x_{c-3}) (nerf/nerf.py:44-49).  Register r of block blk holds feature
 // f0 = 32 blk + (r&3) + 8 (r>>2) on lane half 0 and f0 + 4 on half 1, so (frequency, component, sin|cos) are
 // compile-time constants per half and only a select on h remains at run time.  One v_sin per feature:
-// the argument goes to revolutions with a two-float product (as hw_frac30 does for the activations) and cos is sin shifted by 1/4 turn.
+// the argument goes to revolutions with a two-float product (hw_turns, as for the activations) and cos is sin
+// shifted by 1/4 turn.
 __device__ __forceinline__ float pe_feature(float xv, float scale, float quarter) {
-    const float c_hi = 0.15915494309189535f;                                    // 1 / (2 pi)
-    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
-    const float a = xv * scale;                                                 // exact: scale is a power of two
-    const float hi = a * c_hi;
-    const float lo = fmaf(a, c_hi, -hi) + a * c_lo;
-    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(hi) + lo + quarter);
+#pragma clang fp contract(off)
+    const float r = hw_turns(xv * scale) + quarter;                             // xv * scale exact: a power of two
+    return __builtin_amdgcn_sinf(r - rintf(r));                                 // back to [-1/2, 1/2] after the 1/4 turn
 }
 
 template <int NBLK>

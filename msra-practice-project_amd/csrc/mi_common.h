@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -21,6 +23,27 @@ __device__ __forceinline__ void static_for(F&& f) {
 // error plumbing for the C ABI (api.hip)
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+
+// hipFuncSetAttribute configures the CURRENT device's copy of a kernel, so "once" means once per device ordinal:
+// a process that drives several GPUs (DataParallel's thread per replica, pi_GAN/train.py:50) sets it on each.
+// run(f) calls f() the first time the calling thread's current device is seen (serialised); lock-free afterwards.
+class PerDeviceOnce {
+    std::atomic<uint64_t> done_[4] = {};          // 256 device ordinals
+    std::mutex mu_;
+public:
+    template <class F>
+    int run(F&& f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) { set_error("hipGetDevice failed"); return -2; }
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done_[dev >> 6].load(std::memory_order_acquire) & bit) return 0;
+        std::lock_guard<std::mutex> g(mu_);
+        if (done_[dev >> 6].load(std::memory_order_relaxed) & bit) return 0;
+        const int rc = f();
+        if (rc == 0) done_[dev >> 6].fetch_or(bit, std::memory_order_release);
+        return rc;
+    }
+};
 
 // arguments of the fused field-MLP kernels (field_mlp.hip)
 struct MlpArgs {

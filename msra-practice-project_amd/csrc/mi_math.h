@@ -38,21 +38,34 @@ __device__ __forceinline__ SinCos fast_sincos(float x) {
 
 __device__ __forceinline__ float fast_sin(float x) { return fast_sincos(x).s; }
 
-// sin / cos of 30*u on the hardware transcendental unit (v_sin_f32 / v_cos_f32 take revolutions):
-// t = u * 30/(2 pi) as a two-float product so the fractional part keeps 24 good bits whatever |u|, then
-// v_fract + v_sin.  Measured on MI355X against fp64 over |u| < 40: max abs error 3.8e-7 (the polynomial above:
-// 7e-8) at ~6 instructions instead of ~22.  Used for the SIREN / FiLM activations sin(30 u)
-// (nerf/nerf.py:112, pi_GAN/modules.py:25); the positional encoding keeps the polynomial.
-__device__ __forceinline__ float hw_frac30(float u) {
-    const float c_hi = 4.77464829275686f;                                       // 30 / (2 pi)
-    const float c_lo = (float)(4.774648292756860073 - (double)4.77464829275686f);
-    const float hi = u * c_hi;
-    const float lo = fmaf(u, c_hi, -hi) + u * c_lo;
-    return __builtin_amdgcn_fractf(hi) + lo;
+// sin / cos of 30*u on the hardware transcendental unit (v_sin_f32 / v_cos_f32 take revolutions), for the SIREN /
+// FiLM activations sin(30 u) (nerf/nerf.py:112, pi_GAN/modules.py:25).
+//  * t = fl(30 u) FIRST: the reference evaluates torch.sin(30 * x), i.e. the sine of the ROUNDED product; at
+//    |30 u| ~ 100 (first layers on raw coordinates) that rounding moves the sine by up to 4e-6, so reducing the exact
+//    product instead (as the first version of this file did) is closer to real arithmetic but 10x further from
+//    the reference than the transcendental unit's own error;
+//  * revolutions = t / (2 pi) as a two-float product, reduced to [-1/2, 1/2] (hi - rndne(hi) is exact, the low
+//    part is added to a value whose ulp is <= 3e-8) before v_sin.
+// Measured on MI355X (tools/probes/sin_variants.hip) against sin(fl(30 u)) in fp64 over |u| < 40: max abs error
+// 1.8e-7, rms 4.2e-8 (v_fract instead of the centred reduction: 4.2e-7 / 6.9e-8; libm sinf: 6.9e-8 / 1.8e-8), at
+// 8 instructions instead of libm's ~40 with a Payne-Hanek slow path at every call site.
+// hipcc contracts a*b-c into an fma ACROSS statements by default, which would replace the rounded `hi` below by the
+// exact product and count its low part twice: contraction is off inside these helpers.
+__device__ __forceinline__ float hw_turns(float t) {
+#pragma clang fp contract(off)
+    const float c_hi = 0.15915494309189535f;                                    // 1 / (2 pi)
+    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    const float hi = t * c_hi;
+    const float lo = fmaf(t, c_lo, fmaf(t, c_hi, -hi));
+    return (hi - rintf(hi)) + lo;
 }
-__device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(hw_frac30(u)); }
+__device__ __forceinline__ float hw_turns30(float u) {
+#pragma clang fp contract(off)
+    return hw_turns(30.f * u);
+}
+__device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(hw_turns30(u)); }
 __device__ __forceinline__ SinCos hw_sincos30(float u) {
-    const float f = hw_frac30(u);
+    const float f = hw_turns30(u);
     return {__builtin_amdgcn_sinf(f), __builtin_amdgcn_cosf(f)};
 }
 

@@ -189,6 +189,7 @@ class _RenderRaysFn(torch.autograd.Function):
         raw_f, ctx.acts_f = _forward_pass(pf_f, rays, z_f, film, SAVE_FINE_BYTES)
         rgb_f, depth_f, acc_f, _ = ops.composite(raw_f, z_f, rays, want_weights=False)
         ctx.pf_c, ctx.pf_f, ctx.film = pf_c, pf_f, None if film is None else film.detach()
+        ctx.versions = (pf_c.versions(), pf_f.versions())
         ctx.n_c = len(pf_c.params)
         ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f)
         ctx.set_materialize_grads(False)
@@ -198,6 +199,12 @@ class _RenderRaysFn(torch.autograd.Function):
     def backward(ctx, g_rgb_c, g_depth_c, g_acc_c, g_rgb_f, g_depth_f, g_acc_f):
         rays, z_c, raw_c, z_f, raw_f = ctx.saved_tensors
         pf_c, pf_f = ctx.pf_c, ctx.pf_f
+        if (pf_c.versions(), pf_f.versions()) != ctx.versions:
+            # backward re-reads the live weights (transposed stream, recomputed ranges) while raw and the kept layer
+            # inputs date from the forward: a parameter updated in between would give silently mixed gradients.
+            # PyTorch raises for its own saved tensors in this situation; so do we.
+            raise RuntimeError("render_rays backward: a field parameter was modified in place (or replaced) after the "
+                               "forward pass that this backward belongs to")
         same = pf_c is pf_f
         grads_c = grads_f = gfilm_c = gfilm_f = None
         if any(g is not None for g in (g_rgb_c, g_depth_c, g_acc_c)):

@@ -44,22 +44,31 @@ def all_gather_rays(local: torch.Tensor, total: int, group=None) -> torch.Tensor
     return torch.cat(parts)
 
 
-def render_image_sharded(render_shard, width: int, height: int, group=None):
+def render_image_sharded(render_shard, width: int, height: int, group=None, timing: list | None = None):
     """Render this rank's ray range with `render_shard(ray0, n) -> (rgb[n,3], depth[n], acc[n])` and
-    all-gather the frame.  Returns device tensors rgb[H,W,3], depth[H,W,1], acc[H,W,1] on every rank."""
+    all-gather the frame.  Returns device tensors rgb[H,W,3], depth[H,W,1], acc[H,W,1] on every rank.
+    `timing`: a list that receives one (start, end) pair of torch.cuda.Event per call, recorded on the current
+    stream around the collective (bench.py reports the all-gather's cost from them)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     total = width * height
     a, b = shard_range(total, rank, world)
     rgb, depth, acc = render_shard(a, b - a)
     packed = torch.cat([rgb.reshape(-1, 3), depth.reshape(-1, 1), acc.reshape(-1, 1)], 1)
-    full = all_gather_rays(packed, total, group) if world > 1 else packed
+    if world > 1 and timing is not None and packed.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        full = all_gather_rays(packed, total, group)
+        ev[1].record()
+        timing.append(ev)
+    else:
+        full = all_gather_rays(packed, total, group) if world > 1 else packed
     return (full[:, :3].reshape(height, width, 3), full[:, 3:4].reshape(height, width, 1),
             full[:, 4:5].reshape(height, width, 1))
 
 
 def render_image_dist(width, height, focal, pose, near, far, coarse_model, fine_model, n_coarse, n_fine,
-                      seed=0, t_rand=None, group=None):
+                      seed=0, t_rand=None, group=None, timing: list | None = None):
     """nerf/render.py:150-167 sharded over the process group (fine-pass outputs, device tensors)."""
     from . import render_core
 
@@ -68,7 +77,7 @@ def render_image_dist(width, height, focal, pose, near, far, coarse_model, fine_
         with torch.no_grad():
             return render_core._render_image_device(width, height, focal, pose, near, far, coarse_model, fine_model,
                                                     n_coarse, n_fine, None, tr, seed, ray0, n)
-    return render_image_sharded(shard, width, height, group)
+    return render_image_sharded(shard, width, height, group, timing)
 
 
 def allreduce_grads(params, group=None):

@@ -80,13 +80,32 @@ class PackedField:
     def __init__(self, kind: int, params: list):
         self.kind = kind
         self.params = params                      # live tensors, state-dict order (w0,b0,w1,b1,...)
-        self.device = params[0].device
-        lib = _lib.load()
-        n = lib.mi_field_packed_floats(kind)
-        self.packed = torch.empty(n, dtype=torch.float32, device=self.device)
-        self._versions = None
-        self._versions_bwd = None
+        self.device = None
+        self._follow_device()
+
+    def _follow_device(self):
+        """(Re)allocate the packed streams on the parameters' device: `model.to(other_device)` replaces the
+        parameters' storage in place, so the same PackedField must move with them."""
+        dev = self.params[0].device
+        if dev == self.device:
+            return
+        if dev.type != "cuda":
+            raise _lib.MiRenderError("the fused renderer needs the model on a ROCm device (model.cuda())")
+        self.device = dev
+        self.packed = torch.empty(_lib.load().mi_field_packed_floats(self.kind), dtype=torch.float32, device=dev)
         self.packed_bwd = None
+        self._versions = self._versions_bwd = None
+
+    def versions(self):
+        """(storage pointer, version counter) per parameter: what decides whether the packed streams are stale.
+        In-place updates through torch ops (optimiser steps, load_state_dict, `p.mul_()` under no_grad) bump the
+        counter; writes through `.data` (the reference's `bias.data[:n] = 1`, pi_GAN/modules.py:57-58) do NOT -
+        call invalidate() after such a write."""
+        return tuple((p.data_ptr(), p._version) for p in self.params)
+
+    def invalidate(self):
+        """Force a repack on the next use (after writes the version counters cannot see, e.g. through `.data`)."""
+        self._versions = self._versions_bwd = None
 
     def _sources(self):
         srcs = []
@@ -98,7 +117,8 @@ class PackedField:
 
     def refresh_bwd(self):
         """Transposed weight stream for the backward chain (dX = W^T dA), same lazy refresh."""
-        vers = tuple((p.data_ptr(), p._version) for p in self.params)
+        self._follow_device()
+        vers = self.versions()
         if vers == self._versions_bwd:
             return self.packed_bwd
         lib = _lib.load()
@@ -115,15 +135,12 @@ class PackedField:
         return self.packed_bwd
 
     def refresh(self):
-        vers = tuple((p.data_ptr(), p._version) for p in self.params)
+        self._follow_device()
+        vers = self.versions()
         if vers == self._versions:
             return self.packed
         lib = _lib.load()
-        srcs = []
-        for p in self.params:
-            if p.dtype != torch.float32 or p.device != self.device:
-                raise _lib.MiRenderError("field parameters must be fp32 on one device")
-            srcs.append(p.detach() if p.is_contiguous() else p.detach().contiguous())
+        srcs = self._sources()
         arr = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
         with torch.cuda.device(self.device):
             _lib.check(lib.mi_field_pack(self.kind, arr, len(srcs), _lib.ptr(self.packed),
@@ -136,6 +153,25 @@ class PackedField:
 _field_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
+def _replica_named(model) -> dict:
+    """torch.nn.DataParallel (pi_GAN/train.py:50) runs forward on per-device REPLICAS whose parameters are plain
+    tensor attributes (broadcast copies that still carry autograd history back to the originals), so
+    named_parameters() is empty there.  Walk the known layouts' attribute paths instead."""
+    for kind, spec in SPECS.items():
+        named = {}
+        try:
+            for key, _ in spec:
+                mod = model
+                for part in key.split("."):
+                    mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+                named[key + ".weight"], named[key + ".bias"] = mod.weight, mod.bias
+        except (AttributeError, IndexError, KeyError, TypeError):
+            continue
+        if all(isinstance(t, torch.Tensor) for t in named.values()) and detect_kind(named) == kind:
+            return named
+    return {}
+
+
 def as_packed_field(model) -> PackedField | None:
     """PackedField for a recognised nn.Module (reference class or ours), else None."""
     if isinstance(model, PackedField):
@@ -145,6 +181,8 @@ def as_packed_field(model) -> PackedField | None:
     pf = _field_cache.get(model)
     if pf is None:
         named = dict(model.named_parameters())
+        if not named and getattr(model, "_is_replica", False):
+            named = _replica_named(model)
         kind = detect_kind(named)
         if kind is None:
             _field_cache[model] = False

@@ -15,9 +15,10 @@ from . import _lib
 
 
 def gaussian(window_size: int, sigma: float) -> torch.Tensor:
-    """pytorch_ssim.gaussian (__init__.py:7-10), evaluated on the CPU like the reference does."""
+    """pytorch_ssim.gaussian (__init__.py:7-10).  Always a CPU tensor, whatever the ambient default tensor type
+    (the scripts set torch.cuda.FloatTensor, nerf/test_nerf.py:13): mi_image_metrics takes the window as a HOST array."""
     gauss = torch.tensor([exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)],
-                         dtype=torch.float32)
+                         dtype=torch.float32, device="cpu")
     return gauss / gauss.sum()
 
 
@@ -39,6 +40,8 @@ def image_metrics(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11)
     b = img2.detach().to(torch.float32).contiguous()
     n, c, h, w = a.shape
     win = gaussian(window_size, 1.5).contiguous()
+    if win.device.type != "cpu" or win.dtype != torch.float32:
+        raise _lib.MiRenderError("the SSIM window must be a CPU fp32 tensor (mi_image_metrics reads it on the host)")
     ws = torch.empty(lib.mi_image_metrics_workspace_floats(n, c, h, w), dtype=torch.float32, device=dev)
     out = torch.empty((n, 2), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

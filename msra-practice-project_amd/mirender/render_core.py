@@ -44,8 +44,9 @@ def _device_of(*models, rays=None):
 
 
 def _fresh_seed() -> int:
-    # one draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync
-    return int(torch.randint(0, 2 ** 62, (1,)).item())
+    # one draw from torch's CPU generator: reproducible under torch.manual_seed, no device sync (device="cpu"
+    # explicitly: under the scripts' CUDA default tensor type a bare randint is a device draw + sync)
+    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
 
 
 def get_rays(width, height, focal, c2w):
@@ -171,11 +172,16 @@ def render_image_tensor(width, height, focal, pose, near, far, coarse_model, fin
 
 
 def render_video(width, height, focal, poses, near, far, coarse_model, fine_model, coarse_sample_num,
-                 fine_sample_num, chunk=1024 * 16):
+                 fine_sample_num, chunk=1024 * 16, *, t_rand=None, seed=None):
     """nerf/render.py:170-182 (and the evident intent of pi_GAN/render.py:229-241, whose body unpacks
-    three values from the tensor-returning render_image): stacked NumPy frames."""
-    frames = [render_image(width, height, focal, p, near, far, coarse_model, fine_model, coarse_sample_num,
-                           fine_sample_num, chunk) for p in tqdm(poses)]
+    three values from the tensor-returning render_image): stacked NumPy frames rgb[F,H,W,3], depth[F,H,W,1],
+    acc[F,H,W,1].  Keyword-only extras: `t_rand` [F, H*W, Nc] injects each frame's jitter, `seed` seeds frame i with
+    seed + i (the reference draws every frame's jitter from the global RNG)."""
+    frames = []
+    for i, p in enumerate(tqdm(poses)):
+        frames.append(render_image(width, height, focal, p, near, far, coarse_model, fine_model, coarse_sample_num,
+                                   fine_sample_num, chunk, t_rand=None if t_rand is None else t_rand[i],
+                                   seed=None if seed is None else seed + i))
     return tuple(np.stack([f[k] for f in frames]) for k in range(3))
 
 

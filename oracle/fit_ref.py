@@ -1,0 +1,79 @@
+"""Oracle (test infrastructure): a teacher-field scene and the reference's training loop on the CPU.
+
+No dataset ships with the reference, so the "PSNR within 0.05 dB of the reference" clause of the
+north star is checked on a synthetic scene: images of a fixed seeded TEACHER field rendered by the oracle, a
+student fitted to them with the loop of nerf/train_nerf.py:124-176 (ray batches, render_rays, MSE fine + coarse,
+Adam with the decayed learning rate), once by the caller's renderer and once here by CPU autograd through the
+oracle, same initialisation, same batches, same injected jitter.  Only tests/ and bench.py's reporting import this.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import fields as ofields, render_ref as R, synth
+
+NEAR, FAR = 2.0, 6.0
+
+
+class Scene:
+    """`n_views` training views + one held-out view of a teacher tiny_nerf ("medium" density), res x res pixels."""
+
+    def __init__(self, res=24, n_views=6, nc=16, nf=16, seed=100):
+        self.res, self.nc, self.nf = res, nc, nf
+        self.focal = 1.3875 * res
+        sd_t = synth.state_dict("tiny_nerf", seed=seed, sharp="medium", bias_jitter=0.05)
+        teacher = ofields.make_field("tiny_nerf", sd_t)
+        angles = list(np.linspace(-150.0, 150.0, n_views)) + [17.0]
+        self.poses = [synth.pose_degrees(4.0, float(a), -30.0) for a in angles]
+        self.rays = [torch.from_numpy(R.rays_from_camera(res, res, self.focal, p)) for p in self.poses]
+        imgs = []
+        with torch.no_grad():
+            for i, r in enumerate(self.rays):
+                t = R.render_rays(r, NEAR, FAR, teacher, teacher, 32, 64, synth.t_rand(res * res, 32, seed=7000 + i))
+                imgs.append(t.rgb_f)
+        self.images = imgs                                    # [res*res, 3] each; the last one is held out
+        self.train_rays = torch.cat(self.rays[:-1])
+        self.train_rgb = torch.cat(self.images[:-1])
+        self.student_init = (synth.state_dict("tiny_nerf", seed=seed + 1, bias_jitter=0.02),
+                             synth.state_dict("tiny_nerf", seed=seed + 2, bias_jitter=0.02))
+
+    def batch(self, step: int, batch_size: int):
+        """Deterministic batches: a fixed permutation of all training rays, walked in order (train_nerf.py:140-147)."""
+        n = self.train_rays.shape[0]
+        perm = np.random.Generator(np.random.PCG64(4242)).permutation(n)
+        idx = torch.from_numpy(perm[(step * batch_size) % n:][:batch_size].copy())
+        if idx.numel() < batch_size:
+            idx = torch.from_numpy(perm[:batch_size].copy())
+        return self.train_rays[idx], self.train_rgb[idx], synth.t_rand(batch_size, self.nc, seed=90000 + step)
+
+    def heldout_jitter(self):
+        return synth.t_rand(self.res * self.res, self.nc, seed=555)
+
+
+def lr_at(step, lr0=5e-4, decay=250):
+    return lr0 * (0.1 ** (step / (decay * 1000)))            # train_nerf.py:170-173
+
+
+def fit_cpu(scene: Scene, steps: int, batch_size: int):
+    """The reference loop on CPU autograd through the oracle.  Returns (losses[steps], heldout_psnr, state dicts)."""
+    sd_c = {k: v.clone().requires_grad_(True) for k, v in scene.student_init[0].items()}
+    sd_f = {k: v.clone().requires_grad_(True) for k, v in scene.student_init[1].items()}
+    fc, ff = ofields.make_field("tiny_nerf", sd_c), ofields.make_field("tiny_nerf", sd_f)
+    params = list(sd_c.values()) + list(sd_f.values())
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))                # train_nerf.py:98
+    losses = []
+    for step in range(steps):
+        rays, rgb, tr = scene.batch(step, batch_size)
+        out = R.render_rays(rays, NEAR, FAR, fc, ff, scene.nc, scene.nf, tr)
+        loss = torch.mean((out.rgb_f - rgb) ** 2) + torch.mean((out.rgb_c - rgb) ** 2)      # :158-166
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        for g in opt.param_groups:
+            g["lr"] = lr_at(step + 1)
+        losses.append(float(loss.detach()))
+    with torch.no_grad():
+        held = R.render_rays(scene.rays[-1], NEAR, FAR, fc, ff, scene.nc, scene.nf, scene.heldout_jitter())
+    psnr = R.psnr(held.rgb_f.numpy(), scene.images[-1].numpy())
+    return losses, psnr, ({k: v.detach() for k, v in sd_c.items()}, {k: v.detach() for k, v in sd_f.items()})

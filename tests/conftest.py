@@ -32,3 +32,14 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Every parity check leaves a record (oracle/parity.py): achieved error, gate, which bound was active.  The GPU
+    session writes them under gpurun_out/ (merged back by gpurun); the committed copy is profiles/r02_parity.json."""
+    from oracle import parity
+    out = os.environ.get("MI_PARITY_JSON", os.path.join(ROOT, "gpurun_out", "r02_parity.json"))
+    try:
+        parity.write_records(out)
+    except Exception as e:      # noqa: BLE001  (bookkeeping must never turn a green run red or hide a red one)
+        print(f"parity records not written: {e!r}")

@@ -16,6 +16,7 @@ Fixture families:
   F6 pigan_grad    pi_GAN image + grads wrt FiLM table and field weights
   F7 nerf_grad     nerf training loss grads for one ray batch
   F8 metrics       pytorch_ssim.ssim / mse / psnr of synthetic frame pairs (nerf/test_nerf.py:102-104)
+  F9 video         render_video / render_image / render_image_np over two poses; ref_layouts.json (make_r02)
 """
 import contextlib
 import os
@@ -159,12 +160,121 @@ def make_metrics():
     save("metrics_f8", **out)
 
 
+def trace_render(render_mod, rays, near, far, cm, fm, nc, nf, tr):
+    """Re-run the reference's stages one by one to capture intermediates, then
+    check they reproduce render_rays' own outputs exactly."""
+    with injected_rand([tr]):
+        outs = render_mod.render_rays(rays, near, far, cm, fm, nc, nf)
+    # glue between the reference's stage functions comes from the oracle; the assert
+    # below proves the staged run reproduces render_rays bit for bit.
+    ro, rdd = rays[:, 0], rays[:, 1]
+    vd = rdd / torch.norm(rdd, dim=-1, keepdim=True)
+    zc, mids = oref.stratified_z(rays.shape[0], near, far, nc, tr)
+    raw_c = render_mod.run_network(oref.points_on_rays(ro, rdd, zc), vd, cm)
+    rc = render_mod.raw_to_outputs(raw_c, zc, rdd)
+    zs = render_mod.sample_pdf(mids, rc[3][..., 1:-1], nf)
+    zf = torch.sort(torch.cat([zc, zs], -1), -1).values
+    raw_f = render_mod.run_network(oref.points_on_rays(ro, rdd, zf), vd, fm)
+    rf = render_mod.raw_to_outputs(raw_f, zf, rdd)
+    for a, b in zip(outs, (rc[0], rc[1], rc[2], rf[0], rf[1], rf[2])):
+        assert torch.equal(a, b)
+    return dict(rgb_c=outs[0], depth_c=outs[1], acc_c=outs[2], rgb_f=outs[3], depth_f=outs[4], acc_f=outs[5],
+                z_coarse=zc, raw_c=raw_c, weights_c=rc[3], z_samples=zs, z_fine=zf, raw_f=raw_f,
+                weights_f=rf[3])
+
+
+def pick_rays_from(render_mod, W_, H_, focal_, pose, n_rays, seed):
+    o_, d_ = render_mod.get_rays(W_, H_, focal_, pose)
+    rays = np.stack([o_, d_], 2).reshape(-1, 2, 3).astype(np.float32)
+    idx = np.random.Generator(np.random.PCG64(seed)).choice(rays.shape[0], n_rays, replace=False)
+    return torch.from_numpy(rays[np.sort(idx)])
+
+
+def sharp_tag(sharp, plain=""):
+    return {False: plain, True: "_sharp", "medium": "_medium"}[sharp]
+
+
+def make_r02(nr, nm, nd, pr, pm):
+    """Round-2 additions (the round-1 fixtures above are untouched):
+      F5 twins  the sharp render_rays cases again with the reference's plain initialisation ("") and with the
+                "medium" density head (oracle/synth.py), where the hard 1e-4 gate is the one in force; FiLM fields at
+                12+24 and at the 24+48 samples of BASELINE config C5
+      F9 video  nerf/render.py:170-182 render_video over two poses (and so render_image / pi_GAN's render_image_np)
+      layouts   {class: {parameter name: shape}} of the reference's model classes (ref_layouts.json)"""
+    import json
+    with torch.no_grad():
+        pose = nd.camera_pos_to_transform_matrix(4.0, 63.0, -30.0)
+        for kind, nc, nf, nrays, sharp in (
+            ("nerf", 32, 0, 96, False), ("nerf", 64, 0, 96, False),
+            ("nerf", 32, 0, 96, "medium"), ("nerf", 64, 0, 96, "medium"), ("nerf", 64, 128, 96, "medium"),
+            ("siren_nerf", 64, 128, 64, "medium"),
+        ):
+            rays = pick_rays_from(nr, 100, 100, 1.3875 * 100, pose, nrays, seed=nc + nf)
+            sd_c = synth.state_dict(kind, seed=20, sharp=sharp, bias_jitter=0.05)
+            sd_f = synth.state_dict(kind, seed=21, sharp=sharp, bias_jitter=0.05)
+            cm, fm = ref_model(kind, nm, pm, sd_c), ref_model(kind, nm, pm, sd_f)
+            tr = synth.t_rand(nrays, nc, seed=123)
+            t = trace_render(nr, rays, 2.0, 6.0, cm, fm, nc, nf, tr)
+            save(f"render_f5_{kind}_{nc}_{nf}{sharp_tag(sharp)}", rays=rays, t_rand=tr, near=2.0, far=6.0,
+                 digest_c=np.array(synth.digest(sd_c)), digest_f=np.array(synth.digest(sd_f)), **t)
+        pose_g = pr.camera_pos_to_transform_matrix(1.0, 0.2, -0.1)
+        focal_g = float(32 / 2 / np.tan(12 / 2 * np.pi / 180))
+        o_, d_ = pr.get_rays(32, 32, focal_g, pose_g)
+        rays_g = torch.from_numpy(np.stack([o_, d_], 2).reshape(-1, 2, 3).astype(np.float32)[::8].copy())
+        for kind, nc, nf, sharp in (("film_siren_nerf", 12, 24, False), ("film_siren_nerf", 12, 24, "medium"),
+                                    ("film_siren_nerf_nodir", 12, 24, "medium"),
+                                    ("film_siren_nerf", 24, 48, "medium"), ("film_siren_nerf", 24, 48, True)):
+            sd = synth.state_dict(kind, seed=30, sharp=sharp, bias_jitter=0.0)
+            fl = synth.film_params(1, seed=3)[0]
+            m = ref_model(kind, nm, pm, sd, fl)
+            tr = synth.t_rand(rays_g.shape[0], nc, seed=321)
+            t = trace_render(pr, rays_g, 0.5, 1.5, m, m, nc, nf, tr)
+            # round 1 named its sharp FiLM fixtures without a suffix: the plain-initialisation twin is "_soft"
+            save(f"render_f5_{kind}_{nc}_{nf}{sharp_tag(sharp, '_soft')}", rays=rays_g, t_rand=tr, near=0.5, far=1.5, film=fl,
+                 digest=np.array(synth.digest(sd)), **t)
+
+        # F9: render_video (-> render_image per pose -> render_rays per 16 384-ray chunk; one torch.rand each)
+        W, H, nc, nf = 12, 10, 16, 16
+        poses = [nd.camera_pos_to_transform_matrix(4.0, th, -30.0) for th in (20.0, 200.0)]
+        sd_c = synth.state_dict("nerf", seed=60, sharp="medium", bias_jitter=0.05)
+        sd_f = synth.state_dict("nerf", seed=61, sharp="medium", bias_jitter=0.05)
+        cm, fm = ref_model("nerf", nm, pm, sd_c), ref_model("nerf", nm, pm, sd_f)
+        trs = [synth.t_rand(W * H, nc, seed=900 + i) for i in range(len(poses))]
+        with injected_rand(list(trs)):
+            rgb, depth, acc = nr.render_video(W, H, 1.3875 * W, poses, 2.0, 6.0, cm, fm, nc, nf)
+        with injected_rand([trs[1]]):
+            one = nr.render_image(W, H, 1.3875 * W, poses[1], 2.0, 6.0, cm, fm, nc, nf)
+        with injected_rand([trs[0]]):
+            one_np = pr.render_image_np(W, H, 1.3875 * W, poses[0], 2.0, 6.0, cm, fm, nc, nf)
+        assert np.array_equal(one[0], rgb[1]) and np.array_equal(one_np[0], rgb[0])
+        save("video_f9", W=W, H=H, focal=np.float64(1.3875 * W), near=2.0, far=6.0, n_coarse=nc, n_fine=nf,
+             poses=np.stack(poses), t_rand=torch.stack(trs), rgb=rgb, depth=depth, acc=acc,
+             digest_c=np.array(synth.digest(sd_c)), digest_f=np.array(synth.digest(sd_f)))
+
+    # parameter layouts of the reference's own classes, for fields.detect_kind / pigan.Generator key parity
+    gen = pm.Generator(256, 64)
+    layouts = {
+        "nerf.NeRF": nm.NeRF(), "nerf.SirenNeRF": nm.SirenNeRF(),
+        "pi_GAN.FilmSirenNeRF(use_dir=True)": pm.FilmSirenNeRF(use_dir=True),
+        "pi_GAN.FilmSirenNeRF(use_dir=False)": pm.FilmSirenNeRF(use_dir=False),
+        "pi_GAN.Generator(256, 64)": gen, "pi_GAN.MappingNetwork()": pm.MappingNetwork(),
+    }
+    out = {name: {k: list(v.shape) for k, v in m.named_parameters()} for name, m in layouts.items()}
+    out["pi_GAN.Generator(256, 64).state_dict"] = {k: list(v.shape) for k, v in gen.state_dict().items()}
+    with open(os.path.join(HERE, "ref_layouts.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("ref_layouts.json", {k: len(v) for k, v in out.items()})
+
+
 def main():
     if "--only-metrics" in sys.argv:
         make_metrics()
         return
     torch.set_num_threads(8)
     nr, nm, nd, pr, pm = load_reference()
+    if "--only-r02" in sys.argv:
+        make_r02(nr, nm, nd, pr, pm)
+        return
 
     # ---------------- F1: rays + poses ----------------
     pose_n = nd.camera_pos_to_transform_matrix(4.0, 37.0, -30.0)           # degrees
@@ -233,33 +343,8 @@ def main():
     save("field_f4", **f4)
 
     # ---------------- F5: render_rays with all intermediates ----------------
-    def trace_render(render_mod, rays, near, far, cm, fm, nc, nf, tr):
-        """Re-run the reference's stages one by one to capture intermediates, then
-        check they reproduce render_rays' own outputs exactly."""
-        with injected_rand([tr]):
-            outs = render_mod.render_rays(rays, near, far, cm, fm, nc, nf)
-        # glue between the reference's stage functions comes from the oracle; the assert
-        # below proves the staged run reproduces render_rays bit for bit.
-        ro, rdd = rays[:, 0], rays[:, 1]
-        vd = rdd / torch.norm(rdd, dim=-1, keepdim=True)
-        zc, mids = oref.stratified_z(rays.shape[0], near, far, nc, tr)
-        raw_c = render_mod.run_network(oref.points_on_rays(ro, rdd, zc), vd, cm)
-        rc = render_mod.raw_to_outputs(raw_c, zc, rdd)
-        zs = render_mod.sample_pdf(mids, rc[3][..., 1:-1], nf)
-        zf = torch.sort(torch.cat([zc, zs], -1), -1).values
-        raw_f = render_mod.run_network(oref.points_on_rays(ro, rdd, zf), vd, fm)
-        rf = render_mod.raw_to_outputs(raw_f, zf, rdd)
-        for a, b in zip(outs, (rc[0], rc[1], rc[2], rf[0], rf[1], rf[2])):
-            assert torch.equal(a, b)
-        return dict(rgb_c=outs[0], depth_c=outs[1], acc_c=outs[2], rgb_f=outs[3], depth_f=outs[4], acc_f=outs[5],
-                    z_coarse=zc, raw_c=raw_c, weights_c=rc[3], z_samples=zs, z_fine=zf, raw_f=raw_f,
-                    weights_f=rf[3])
-
     def pick_rays(W_, H_, focal_, pose, n_rays, seed):
-        o_, d_ = nr.get_rays(W_, H_, focal_, pose)
-        rays = np.stack([o_, d_], 2).reshape(-1, 2, 3).astype(np.float32)
-        idx = np.random.Generator(np.random.PCG64(seed)).choice(rays.shape[0], n_rays, replace=False)
-        return torch.from_numpy(rays[np.sort(idx)])
+        return pick_rays_from(nr, W_, H_, focal_, pose, n_rays, seed)
 
     with torch.no_grad():
         pose = nd.camera_pos_to_transform_matrix(4.0, 63.0, -30.0)
@@ -333,6 +418,7 @@ def main():
          loss=loss, rgb_c=rgb_c, acc_c=acc_c, rgb_f=rgb_f, acc_f=acc_f,
          digest_c=np.array(synth.digest(sd_c)), digest_f=np.array(synth.digest(sd_f)), **grad_summary(named))
     make_metrics()
+    make_r02(nr, nm, nd, pr, pm)
     print("specs:", {k: len(v) for k, v in SPECS.items()})
 
 

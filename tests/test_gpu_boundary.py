@@ -1,0 +1,118 @@
+"""GPU: corners of the drop-in boundary: DataParallel replicas, stale-weight detection, models that
+move between devices, per-device kernel attributes."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import render_ref as R, synth  # noqa: E402
+
+
+def dev(i=0):
+    return torch.device("cuda", i)
+
+
+def _rays(n=256, d=None):
+    return torch.from_numpy(R.rays_from_camera(24, 24, 33.3, synth.pose_degrees(4.0, 25.0, -30.0))[100:100 + n]).to(d or dev())
+
+
+def test_data_parallel_replica_is_recognised_and_trains():
+    """torch.nn.DataParallel (pi_GAN/train.py:50) calls forward on replicas whose parameters are plain broadcast
+    tensors: named_parameters() is empty there.  The replica must take the fused path (not fall through to the
+    generic one) and gradients must flow back to the original module's parameters."""
+    from mirender import fields, pigan, render_core
+    m = fields.FilmSirenNeRF().to(dev())
+    m.load_state_dict(synth.state_dict("film_siren_nerf", seed=40, sharp="medium"))
+    (rep,) = torch.nn.parallel.replicate(m, [0])
+    assert getattr(rep, "_is_replica", False) and not dict(rep.named_parameters())
+    pf = fields.as_packed_field(rep)
+    assert pf is not None and pf.kind == fields.FILM_SIREN_NERF
+    film = synth.film_params(1, seed=3).to(dev())
+    rays = torch.from_numpy(R.rays_from_camera(12, 12, 57.0, pigan.camera_pos_to_transform_matrix(1, 0.1, -0.1))).to(dev())
+    tr = synth.t_rand(144, 6, seed=1).to(dev())
+    out_r = render_core.render_rays(rays, 0.5, 1.5, rep, rep, 6, 12, t_rand=tr, film=film)
+    out_m = render_core.render_rays(rays, 0.5, 1.5, m, m, 6, 12, t_rand=tr, film=film)
+    assert out_r[3].requires_grad and torch.equal(out_r[3].detach(), out_m[3].detach())
+    out_r[3].square().mean().backward()
+    g_rep = [p.grad.clone() for p in m.parameters()]          # through Broadcast.backward onto the originals
+    for p in m.parameters():
+        p.grad = None
+    out_m[3].square().mean().backward()
+    for a, p in zip(g_rep, m.parameters()):
+        assert a is not None and torch.equal(a, p.grad)
+    # a whole Generator under DataParallel on this one device (device_ids=[0] calls the module itself)
+    torch.manual_seed(0)
+    gen = pigan.Generator(16, 12, near=0.5, far=1.5, fov=12, coarse_samples=6, fine_samples=12).to(dev())
+    dp = torch.nn.DataParallel(gen, device_ids=[0])
+    z = torch.randn(2, 16, device=dev())
+    img = dp(z, [0.1, 0.2], [0.0, 0.1], tr.repeat(2, 1))
+    assert tuple(img.shape) == (2, 3, 12, 12) and img.requires_grad
+
+
+def test_weights_changed_between_forward_and_backward_raise():
+    from mirender import fields, render_core
+    m = fields.TinyNeRF().to(dev())
+    m.load_state_dict(synth.state_dict("tiny_nerf", 3, "medium", 0.05))
+    rays, tr = _rays(), synth.t_rand(256, 8, 1).to(dev())
+    out = render_core.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    with torch.no_grad():
+        m.layers_pos[1].weight.mul_(1.01)                       # e.g. an optimiser step before backward
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out[3].sum().backward()
+    # writes through .data are invisible to version counters: invalidate() is the documented way to repack
+    with torch.no_grad():
+        before = m(torch.rand(64, 6, device=dev()) * 0 + 0.3)
+    m.output_layer_rgb.bias.data[:] = 2.0                        # the reference's own idiom, pi_GAN/modules.py:57-58
+    fields.as_packed_field(m).invalidate()
+    with torch.no_grad():
+        after = m(torch.rand(64, 6, device=dev()) * 0 + 0.3)
+    assert float((after[:, :3] - before[:, :3]).abs().min()) > 1e-3
+
+
+def test_model_moved_to_cpu_and_back_repacks():
+    from mirender import _lib, fields
+    m = fields.NeRF().to(dev())
+    m.load_state_dict(synth.state_dict("nerf", 5, "medium", 0.05))
+    x = torch.rand(100, 6, device=dev()) * 2 - 1
+    with torch.no_grad():
+        a = m(x)
+    m.cpu()
+    with pytest.raises(_lib.MiRenderError):
+        m(x)                                                     # no CPU path: a clear error, not a stale render
+    m.to(dev())
+    with torch.no_grad():
+        b = m(x)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs in one process (DataParallel's layout)")
+def test_two_devices_two_threads_one_process():
+    """One process driving two GPUs from two threads (pi_GAN/train.py:50): the 148 KiB dynamic-LDS attribute of the
+    MLP kernels is per device (csrc/mi_common.h:PerDeviceOnce); both devices must render, train and agree."""
+    from mirender import fields, render_core
+    sd = synth.state_dict("nerf", 5, "medium", 0.05)
+    outs, errs = [None, None], []
+
+    def work(i):
+        try:
+            with torch.cuda.device(i):
+                m = fields.NeRF().to(dev(i))
+                m.load_state_dict(sd)
+                rays, tr = _rays(256, dev(i)), synth.t_rand(256, 8, 1).to(dev(i))
+                o = render_core.render_rays(rays, 2.0, 6.0, m, m, 8, 16, t_rand=tr)
+                (o[3].square().mean() + o[0].square().mean()).backward()
+                torch.cuda.synchronize(i)
+                outs[i] = [t.detach().cpu() for t in o] + [p.grad.cpu() for p in m.parameters()]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for a, b in zip(*outs):
+        assert np.array_equal(a.numpy(), b.numpy())

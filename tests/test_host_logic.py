@@ -104,3 +104,64 @@ def test_pigan_generator_state_dict_layout():
     assert abs(float(r.focal) - 16 / 2 / np.tan(6 * np.pi / 180)) < 1e-9
     g.set_resolution(32)
     assert r.width == 32 and abs(float(r.focal) - 32 / 2 / np.tan(6 * np.pi / 180)) < 1e-9
+
+
+def test_reference_class_layouts_are_recognised():
+    """tests/golden/ref_layouts.json = {name: shape} of named_parameters() of the REFERENCE's own classes
+    (nerf/nerf.py NeRF, SirenNeRF; pi_GAN/modules.py FilmSirenNeRF(use_dir=+-), Generator, MappingNetwork), dumped by
+    tests/golden/make_golden.py in the build container.  detect_kind must recognise each field class, and our
+    Generator / MappingNetwork must carry exactly the reference's state-dict keys and shapes."""
+    import json
+    import os
+    from mirender import fields, pigan
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_layouts.json")) as f:
+        ref = json.load(f)
+    expect = {"nerf.NeRF": fields.NERF, "nerf.SirenNeRF": fields.SIREN_NERF,
+              "pi_GAN.FilmSirenNeRF(use_dir=True)": fields.FILM_SIREN_NERF,
+              "pi_GAN.FilmSirenNeRF(use_dir=False)": fields.FILM_SIREN_NERF_NODIR}
+    for name, kind in expect.items():
+        named = {k: torch.empty(s) for k, s in ref[name].items()}
+        assert fields.detect_kind(named) == kind, name
+        ours = {fields.NERF: fields.NeRF, fields.SIREN_NERF: fields.SirenNeRF, fields.FILM_SIREN_NERF: fields.FilmSirenNeRF,
+                fields.FILM_SIREN_NERF_NODIR: lambda: fields.FilmSirenNeRF(use_dir=False)}[kind]()
+        assert {k: list(v.shape) for k, v in ours.named_parameters()} == ref[name]
+        assert list(dict(ours.named_parameters())) == list(ref[name]) or sorted(dict(ours.named_parameters())) == sorted(ref[name])
+    g = pigan.Generator(256, 64)
+    assert {k: list(v.shape) for k, v in g.state_dict().items()} == ref["pi_GAN.Generator(256, 64).state_dict"]
+    assert {k: list(v.shape) for k, v in g.named_parameters()} == ref["pi_GAN.Generator(256, 64)"]
+    assert {k: list(v.shape) for k, v in pigan.MappingNetwork().named_parameters()} == ref["pi_GAN.MappingNetwork()"]
+    # the field inside a reference Generator is found under its attribute name
+    inner = {k[len("film_siren_nerf."):]: torch.empty(s) for k, s in ref["pi_GAN.Generator(256, 64)"].items()
+             if k.startswith("film_siren_nerf.")}
+    assert fields.detect_kind(inner) == fields.FILM_SIREN_NERF
+
+
+def test_bench_spawns_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` from a plain shell (no torch.distributed.run environment) must start N fresh rank
+    processes itself - before any GPU call, never by re-exec'ing - and relay their exit code."""
+    import os
+    import sys
+    import bench
+    cmd = bench.spawn_command(["--gpus", "4", "--steps", "3", "--warmup", "1"], 4, 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(c, env=None, **kw):
+        seen["cmd"], seen["env"] = c, env
+        return Done()
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "2"])
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("parent touched the GPU")))
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["cmd"][-4:] == ["--gpus", "2", "--steps", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

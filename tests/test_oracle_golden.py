@@ -82,6 +82,11 @@ F5 = [
     ("render_f5_nerf_64_128_sharp", "nerf", 64, 128, True),
     ("render_f5_nerf_64_128", "nerf", 64, 128, False),
     ("render_f5_siren_nerf_64_128", "siren_nerf", 64, 128, False),
+    # round 2: plain-initialisation and "medium"-density twins of the sharp cases (make_golden.py:make_r02)
+    ("render_f5_nerf_32_0", "nerf", 32, 0, False), ("render_f5_nerf_64_0", "nerf", 64, 0, False),
+    ("render_f5_nerf_32_0_medium", "nerf", 32, 0, "medium"), ("render_f5_nerf_64_0_medium", "nerf", 64, 0, "medium"),
+    ("render_f5_nerf_64_128_medium", "nerf", 64, 128, "medium"),
+    ("render_f5_siren_nerf_64_128_medium", "siren_nerf", 64, 128, "medium"),
 ]
 
 
@@ -99,16 +104,42 @@ def test_f5_render_rays(golden, name, kind, nc, nf, sharp):
         close(getattr(tr, key), g[key], 2e-6)
 
 
-@pytest.mark.parametrize("kind", ["film_siren_nerf", "film_siren_nerf_nodir"])
-def test_f5_render_rays_pigan(golden, kind):
-    g = golden(f"render_f5_{kind}_12_24")
-    sd = synth.state_dict(kind, seed=30, sharp=True)
+@pytest.mark.parametrize("name,kind,nc,nf,sharp", [
+    ("render_f5_film_siren_nerf_12_24", "film_siren_nerf", 12, 24, True),
+    ("render_f5_film_siren_nerf_nodir_12_24", "film_siren_nerf_nodir", 12, 24, True),
+    ("render_f5_film_siren_nerf_12_24_soft", "film_siren_nerf", 12, 24, False),
+    ("render_f5_film_siren_nerf_12_24_medium", "film_siren_nerf", 12, 24, "medium"),
+    ("render_f5_film_siren_nerf_nodir_12_24_medium", "film_siren_nerf_nodir", 12, 24, "medium"),
+    ("render_f5_film_siren_nerf_24_48_medium", "film_siren_nerf", 24, 48, "medium"),
+    ("render_f5_film_siren_nerf_24_48_sharp", "film_siren_nerf", 24, 48, True)])
+def test_f5_render_rays_pigan(golden, name, kind, nc, nf, sharp):
+    g = golden(name)
+    sd = synth.state_dict(kind, seed=30, sharp=sharp)
     assert synth.digest(sd) == str(g["digest"])
     f = fields.make_field(kind, sd, torch.from_numpy(g["film"]))
     with torch.no_grad():
-        tr = R.render_rays(torch.from_numpy(g["rays"]), 0.5, 1.5, f, f, 12, 24, torch.from_numpy(g["t_rand"]))
+        tr = R.render_rays(torch.from_numpy(g["rays"]), 0.5, 1.5, f, f, nc, nf, torch.from_numpy(g["t_rand"]))
     for key in tr._fields:
         close(getattr(tr, key), g[key], 2e-6)
+
+
+def test_f9_render_video(golden):
+    """The reference's render_video / render_image / render_image_np over two poses (nerf/render.py:150-182,
+    pi_GAN/render.py:209-226) against the oracle's render_image with the same injected jitter."""
+    g = golden("video_f9")
+    W, H, nc, nf = int(g["W"]), int(g["H"]), int(g["n_coarse"]), int(g["n_fine"])
+    sd_c = synth.state_dict("nerf", seed=60, sharp="medium", bias_jitter=0.05)
+    sd_f = synth.state_dict("nerf", seed=61, sharp="medium", bias_jitter=0.05)
+    assert synth.digest(sd_c) == str(g["digest_c"]) and synth.digest(sd_f) == str(g["digest_f"])
+    fc, ff = fields.make_field("nerf", sd_c), fields.make_field("nerf", sd_f)
+    assert g["rgb"].shape == (2, H, W, 3) and g["depth"].shape == (2, H, W, 1) and g["acc"].shape == (2, H, W, 1)
+    for i, pose in enumerate(g["poses"]):
+        with torch.no_grad():
+            rgb, depth, acc = R.render_image(W, H, float(g["focal"]), pose, float(g["near"]), float(g["far"]), fc, ff, nc, nf,
+                                             torch.from_numpy(g["t_rand"][i]))
+        close(rgb, g["rgb"][i], 2e-6)
+        close(depth, g["depth"][i], 2e-6)
+        close(acc, g["acc"][i], 2e-6)
 
 
 def _check_grads(g, prefix, named):

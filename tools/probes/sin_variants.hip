@@ -1,0 +1,69 @@
+// Diagnostic (not part of the product): accuracy of sin(30 u) variants on the transcendental unit vs fp64.
+// build: hipcc --offload-arch=gfx950 -O2 tools/probes/sin_variants.hip -o gpurun_tools/sin_variants
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+// t = fl(30 u) as torch.sin(30 * x) sees it; revolutions = t / (2 pi) as a two-float product (no contraction of hi)
+// hipcc contracts a*b-c into fma across statements by default (__fmul_rn is a plain *): the reductions below need
+// the ROUNDED product, so contraction is switched off for this file's arithmetic.
+#pragma clang fp contract(off)
+__device__ __forceinline__ void two_prod(float u, float& hi, float& lo) {
+    const float c_hi = 0.15915494309189535f;
+    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    const float t = __fmul_rn(30.f, u);
+    hi = __fmul_rn(t, c_hi);
+    lo = fmaf(t, c_lo, fmaf(t, c_hi, -hi));
+}
+__device__ float v0(float u) { float hi, lo; two_prod(u, hi, lo); return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(hi) + lo); }
+__device__ float v1(float u) { float hi, lo; two_prod(u, hi, lo); return __builtin_amdgcn_sinf(__fadd_rn(__fsub_rn(hi, rintf(hi)), lo)); }
+__device__ float v2(float u) {
+    float hi, lo; two_prod(u, hi, lo);
+    const float r = __fadd_rn(__fsub_rn(hi, rintf(hi)), lo);
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fmed3f(r, 0.5f - r, -0.5f - r));
+}
+__device__ float v3(float u) {   // fold + polynomial for sin(2 pi r), |r| <= 1/4
+    float hi, lo; two_prod(u, hi, lo);
+    float r = __fadd_rn(__fsub_rn(hi, rintf(hi)), lo);
+    r = __builtin_amdgcn_fmed3f(r, 0.5f - r, -0.5f - r);
+    const float s = r * r;
+    float p = fmaf(s, 39.76049716f, -76.58125642f);      // least-squares fit on Chebyshev nodes: 6.7e-9 max error
+    p = fmaf(p, s, 81.60247959f);
+    p = fmaf(p, s, -41.34168065f);
+    p = fmaf(p, s, 6.28318528f);
+    return p * r;
+}
+__device__ float v4(float u) { return sinf(30.f * u); }   // libm on the product rounded to fp32 (what torch.sin(30*x) sees)
+__global__ void run(const float* u, float* o, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    o[0 * n + i] = v0(u[i]); o[1 * n + i] = v1(u[i]); o[2 * n + i] = v2(u[i]); o[3 * n + i] = v3(u[i]); o[4 * n + i] = v4(u[i]);
+}
+int main() {
+    const int n = 1 << 22, nv = 5;
+    std::vector<float> u(n), o((size_t)nv * n);
+    srand(1);
+    for (int i = 0; i < n; ++i) u[i] = (float)((rand() / (double)RAND_MAX * 2 - 1) * (i % 4 == 0 ? 40.0 : i % 4 == 1 ? 4.0 : i % 4 == 2 ? 0.5 : 0.05));
+    float *du, *dout;
+    (void)hipMalloc(&du, n * 4); (void)hipMalloc(&dout, (size_t)nv * n * 4);
+    (void)hipMemcpy(du, u.data(), n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, du, dout, n);
+    (void)hipMemcpy(o.data(), dout, (size_t)nv * n * 4, hipMemcpyDeviceToHost);
+    const char* names[] = {"v0 fract (current)", "v1 centred", "v2 centred+fold", "v3 fold+poly", "v4 libm sinf(30u)"};
+    for (int v = 0; v < nv; ++v) {
+        double mx = 0, ss = 0;
+        for (int i = 0; i < n; ++i) {
+            // reference: sin of the fp32-rounded product 30*u evaluated exactly (what the fp32 oracle computes) and of the exact product
+            const double e = (double)o[(size_t)v * n + i] - sin(30.0 * (double)u[i]);
+            mx = fmax(mx, fabs(e)); ss += e * e;
+        }
+        double mx2 = 0, ss2 = 0;
+        for (int i = 0; i < n; ++i) {
+            const double e = (double)o[(size_t)v * n + i] - sin((double)(30.f * u[i]));
+            mx2 = fmax(mx2, fabs(e)); ss2 += e * e;
+        }
+        printf("%-22s vs sin(30u exact): max %.3e rms %.3e | vs sin(fl(30u)): max %.3e rms %.3e\n", names[v], mx, sqrt(ss / n), mx2, sqrt(ss2 / n));
+    }
+    return 0;
+}
