@@ -180,7 +180,8 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         n, nc, nf = 1024, 64, 128
         coarse, fine = make_models(dev)
         params = list(coarse.parameters()) + list(fine.parameters())
-        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999), fused=True)     # train_nerf.py:96, one launch
+        # train_nerf.py:98's Adam, fused with the repack of both MFMA weight streams of both models: one launch
+        opt = train.FusedAdam([coarse, fine], lr=5e-4, betas=(0.9, 0.999))
         rays = torch.randn(n, 2, 3, device=dev)
         rays[:, 0] = torch.tensor([0.0, 0.0, 4.0], device=dev)
         rays[:, 1, 2] = -1.0
@@ -195,7 +196,7 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
             loss.backward()
             mdist.allreduce_grads(params)
             opt.step()
-        name = "nerf/train_nerf.py step: 1024 rays/GPU, 64+128 samples, coarse+fine NeRF 8x256, fwd+bwd+Adam"
+        name = "nerf/train_nerf.py step: 1024 rays/GPU, 64+128 samples, coarse+fine NeRF 8x256, fwd+bwd+fused Adam"
 
     def sync():
         if world > 1:

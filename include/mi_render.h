@@ -206,9 +206,24 @@ int mi_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float*
 /* The rays_rgba batching table of nerf/train_nerf.py:78-82 built on the device: row image*H*W + pixel =
  * (rays_o, rays_d of get_rays(width, height, focal, pose[image]), r, g, b, a); white_bkgd != 0 composites rgb on
  * white first (rgb*a + 1 - a, train_nerf.py:64-68).  poses [images,12] = c2w[:3,:4] row-major (device),
- * rgba [images,height,width,4] (device); out rays_rgba [images*height*width,10]. */
-int mi_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd,
-                int64_t images, float* rays_rgba, void* stream);
+ * rgba [images,height,width,4] (device); out rays_rgba [images*height*width,10].  compute_f64 as in mi_gen_rays:
+ * nonzero when the script's focal is an np.float64 scalar (nerf/data_loader.py:151 returns one), which makes
+ * NumPy >= 2 evaluate get_rays in fp64 before train_nerf.py:84 rounds to fp32. */
+int mi_ray_bank(int width, int height, double focal, const float* poses, const float* rgba, int white_bkgd,
+                int64_t images, float* rays_rgba, int compute_f64, void* stream);
+
+/* One optimiser step of torch.optim.Adam(betas, eps; no weight decay, no amsgrad) - nerf/train_nerf.py:98,168 - on the
+ * parameters of 1 or 2 fields, fused with the refresh of their packed weight streams: every tensor's (param, exp_avg,
+ * exp_avg_sq) is updated in place and each new parameter value is written to the positions of the field's forward
+ * stream (mi_field_pack layout) and, when packed_bwd[f] is non-null, its transposed stream (mi_field_pack_bwd) that
+ * hold it.  kinds[n_fields]; params / grads / exp_avg / exp_avg_sq / numel: one entry per tensor, field 0's
+ * mi_field_num_params(kind) tensors first, in mi_field_pack order.  The scalars are torch's, computed by the caller in
+ * double: step_size = -lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t).  The streams must already
+ * hold the current parameters (their padding entries are not rewritten). */
+int mi_adam_step(int n_fields, const int* kinds, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const int64_t* numel, float step_size, float one_minus_beta1, float beta2,
+                 float one_minus_beta2, float eps, float bias_correction2_sqrt, float* const* packed_fwd,
+                 float* const* packed_bwd, void* stream);
 
 /* ---- measurement hooks (bench.py) ---------------------------------------------------- */
 

@@ -71,7 +71,7 @@ using namespace mi;
 
 extern "C" {
 
-int mi_abi_version(void) { return 1; }
+int mi_abi_version(void) { return 2; }
 const char* mi_last_error(void) { return g_err; }
 
 int mi_field_num_params(int kind) { return bad_kind(kind) ? MI_EINVAL : 2 * kNumLayers[kind]; }
@@ -290,13 +290,37 @@ int mi_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float*
                             g_acc_f, workspace, out, (hipStream_t)stream);
 }
 
-int mi_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd, int64_t images,
-                float* rays_rgba, void* stream) {
+int mi_ray_bank(int width, int height, double focal, const float* poses, const float* rgba, int white_bkgd, int64_t images,
+                float* rays_rgba, int compute_f64, void* stream) {
     if (width <= 0 || height <= 0 || images < 0 || !poses || !rgba || (images > 0 && !rays_rgba)) {
         set_error("mi_ray_bank: bad arguments");
         return MI_EINVAL;
     }
-    return launch_ray_bank(width, height, focal, poses, rgba, white_bkgd, images, rays_rgba, (hipStream_t)stream);
+    return launch_ray_bank(width, height, focal, poses, rgba, white_bkgd, images, rays_rgba, compute_f64, (hipStream_t)stream);
+}
+
+int mi_adam_step(int n_fields, const int* kinds, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const int64_t* numel, float step_size, float one_minus_beta1, float beta2,
+                 float one_minus_beta2, float eps, float bias_correction2_sqrt, float* const* packed_fwd,
+                 float* const* packed_bwd, void* stream) {
+    if (n_fields < 1 || n_fields > 2 || !kinds || !params || !grads || !exp_avg || !exp_avg_sq || !numel || !packed_fwd) {
+        set_error("mi_adam_step: bad arguments (1 or 2 fields, non-null tables)");
+        return MI_EINVAL;
+    }
+    int n_params[2] = {0, 0}, total = 0;
+    for (int f = 0; f < n_fields; ++f) {
+        if (bad_kind(kinds[f])) return MI_EINVAL;
+        if (!packed_fwd[f]) { set_error("mi_adam_step: field %d has no packed stream", f); return MI_EINVAL; }
+        n_params[f] = 2 * kNumLayers[kinds[f]];
+        total += n_params[f];
+    }
+    for (int t = 0; t < total; ++t)
+        if (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t] || numel[t] < 0) {
+            set_error("mi_adam_step: tensor %d has a null pointer", t);
+            return MI_EINVAL;
+        }
+    return launch_adam_step(n_fields, kinds, n_params, params, grads, exp_avg, exp_avg_sq, numel, step_size, one_minus_beta1,
+                            beta2, one_minus_beta2, eps, bias_correction2_sqrt, packed_fwd, packed_bwd, (hipStream_t)stream);
 }
 
 void* mi_event_create(void) {

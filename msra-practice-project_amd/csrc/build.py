@@ -22,6 +22,7 @@ SOURCES = {
     # un-fused mul/add like the torch / NumPy ops these kernels restate
     "render_stages.hip": ["-ffp-contract=off"],
     "eval_stages.hip": ["-ffp-contract=off"],
+    "adam_step.hip": [],
     "api.hip": [],
 }
 HEADERS = ["field_layout.h", "mi_common.h", "mi_math.h", "field_mlp_device.h", os.path.join("..", "..", "include", "mi_render.h")]

@@ -246,7 +246,11 @@ int launch_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const fl
 // there) and, as train_nerf.py:64-68 does for the training set, rgb composited on white: rgb*a + (1 - a).
 // poses [images][12] = c2w[:3,:4] row-major, rgba [images][H][W][4].  out [images*H*W][10].
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ray_bank_kernel(int width, int height, float focal, const float* __restrict__ poses,
+// T = float: `focal` is a Python float (all-fp32 NumPy math); T = double: `focal` is an np.float64 scalar - what
+// nerf/data_loader.py:151 returns and train_nerf.py:78 passes - so NumPy >= 2 evaluates get_rays in fp64 and the
+// script rounds to fp32 afterwards (train_nerf.py:84); same switch as gen_rays_kernel (render_stages.hip).
+template <class T>
+__global__ __launch_bounds__(256) void ray_bank_kernel(int width, int height, T focal, const float* __restrict__ poses,
                                                        const float* __restrict__ rgba, int white_bkgd, int64_t n,
                                                        float* __restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -254,13 +258,13 @@ __global__ __launch_bounds__(256) void ray_bank_kernel(int width, int height, fl
     const int64_t hw = (int64_t)width * height;
     const int64_t img = r / hw, pix = r % hw;
     const float* m = poses + img * 12;
-    const float half_w = (float)width / 2.f, half_h = (float)height / 2.f;       // get_rays: width / 2 in Python floats
-    const float x = ((float)(pix % width) - half_w) / focal;
-    const float y = -((float)(pix / width) - half_h) / focal;
+    const T half_w = (T)width / (T)2, half_h = (T)height / (T)2;                 // get_rays: width / 2 in Python floats
+    const T x = ((T)(float)(pix % width) - half_w) / focal;
+    const T y = -((T)(float)(pix / width) - half_h) / focal;
     float* o = out + r * 10;
     o[0] = m[3]; o[1] = m[7]; o[2] = m[11];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) o[3 + c] = (x * m[4 * c + 0] + y * m[4 * c + 1]) + (-1.f) * m[4 * c + 2];
+    for (int c = 0; c < 3; ++c) o[3 + c] = (float)((x * (T)m[4 * c + 0] + y * (T)m[4 * c + 1]) + (T)-1 * (T)m[4 * c + 2]);
     const float* px = rgba + r * 4;
     const float a = px[3];
 #pragma unroll
@@ -268,12 +272,15 @@ __global__ __launch_bounds__(256) void ray_bank_kernel(int width, int height, fl
     o[9] = a;
 }
 
-int launch_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd,
-                    int64_t images, float* out, hipStream_t stream) {
+int launch_ray_bank(int width, int height, double focal, const float* poses, const float* rgba, int white_bkgd,
+                    int64_t images, float* out, int compute_f64, hipStream_t stream) {
     const int64_t n = images * width * height;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(ray_bank_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, width, height, focal, poses,
-                       rgba, white_bkgd, n, out);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (compute_f64)
+        hipLaunchKernelGGL(ray_bank_kernel<double>, grid, block, 0, stream, width, height, focal, poses, rgba, white_bkgd, n, out);
+    else
+        hipLaunchKernelGGL(ray_bank_kernel<float>, grid, block, 0, stream, width, height, (float)focal, poses, rgba, white_bkgd, n, out);
     return check_launch("ray_bank");
 }
 

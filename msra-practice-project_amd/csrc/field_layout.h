@@ -38,6 +38,8 @@ struct PackItem {
     int n_valid;       // VEC/PLAIN: valid features; CHUNK: valid K columns (<=32)
     int rows_valid;    // CHUNK: valid MFMA rows
     int mb;            // CHUNK: MFMA row blocks (8 or 4)
+    int row0, col0;    // coordinates, in the [out, in] weight matrix (bias: [n, 1]), of the item's first element: the
+                       // inverse map (parameter element -> stream position) of adam_step.hip needs no division by them
 };
 
 constexpr int kMaxItems = 112;
@@ -75,20 +77,20 @@ struct TableBuilder {
         off += floats;
     }
     // bias of layer i (n outputs)
-    constexpr void bias(int layer, int n) { push({ITEM_VEC, 2 * layer + 1, 0, 0, 1, n, 0, 0}, kPiece); }
+    constexpr void bias(int layer, int n) { push({ITEM_VEC, 2 * layer + 1, 0, 0, 1, n, 0, 0, 0, 0}, kPiece); }
     // row `row` of weight of layer i as a vector over its n input features starting at col0
     constexpr void wrow(int layer, int ld, int row, int col0, int n) {
-        push({ITEM_VEC, 2 * layer, ld, row * ld + col0, 1, n, 0, 0}, kPiece);
+        push({ITEM_VEC, 2 * layer, ld, row * ld + col0, 1, n, 0, 0, row, col0}, kPiece);
     }
     // column `col` of weight of layer i as a vector over its n output features
-    constexpr void wcol(int layer, int ld, int col, int n) { push({ITEM_VEC, 2 * layer, ld, col, ld, n, 0, 0}, kPiece); }
+    constexpr void wcol(int layer, int ld, int col, int n) { push({ITEM_VEC, 2 * layer, ld, col, ld, n, 0, 0, 0, col}, kPiece); }
     // first n entries of bias of layer i, unpacked at [0..n)
-    constexpr void scalars(int layer, int n) { push({ITEM_PLAIN, 2 * layer + 1, 0, 0, 1, n, 0, 0}, kPiece); }
+    constexpr void scalars(int layer, int n) { push({ITEM_PLAIN, 2 * layer + 1, 0, 0, 1, n, 0, 0, 0, 0}, kPiece); }
     // K blocks of weight of layer i covering columns [col0, col0+ncols)
     constexpr void chunks(int layer, int ld, int col0, int ncols, int rows, int mb) {
         for (int c = 0; c < ncols; c += 32) {
             int nv = ncols - c < 32 ? ncols - c : 32;
-            push({ITEM_CHUNK, 2 * layer, ld, col0 + c, 1, nv, rows, mb}, mb * 1024);
+            push({ITEM_CHUNK, 2 * layer, ld, col0 + c, 1, nv, rows, mb, 0, col0 + c}, mb * 1024);
         }
     }
     // K blocks of the TRANSPOSED weight of layer i for the backward chain dX = W^T dA:
@@ -96,7 +98,7 @@ struct TableBuilder {
     constexpr void chunks_t(int layer, int ld, int hcol0, int rows, int n_out, int mb) {
         for (int c = 0; c < n_out; c += 32) {
             int nv = n_out - c < 32 ? n_out - c : 32;
-            push({ITEM_CHUNK, 2 * layer, 1, hcol0 + c * ld, ld, nv, rows, mb}, mb * 1024);
+            push({ITEM_CHUNK, 2 * layer, 1, hcol0 + c * ld, ld, nv, rows, mb, c, hcol0}, mb * 1024);
         }
     }
 };
@@ -225,20 +227,19 @@ constexpr RegionLayout nerf_grads() { return {11, {256, 256, 256, 256, 256, 256,
 constexpr RegionLayout tiny_acts() { return {7, {64, 256, 256, 256, 256, 32, 128}}; }
 constexpr RegionLayout tiny_grads() { return {6, {256, 256, 256, 256, 128, 4}}; }
 
-// SirenNeRF acts: 0 xin(8: xyz, dir, 0, 0) | layer l=1..8: 2l-1 X_l = sin(30 A_{l-1}), 2l C_l = 30 cos(30 A_{l-1}) |
-//                 17 G (layers_dir.0 out) | 18 X_d (128) | 19 C_d (128).   grads: as NeRF.
-constexpr RegionLayout siren_acts() {
-    return {20, {8, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 128}};
-}
+// SirenNeRF acts: 0 xin(8: xyz, dir, 0, 0) | l = 1..8: X_l = sin(30 A_{l-1}) with the sign of cos(30 A_{l-1}) in its
+//                 lowest mantissa bit (mi_math.h: the derivative factor 30 cos is rebuilt from it, not stored) |
+//                 9 G (layers_dir.0 out) | 10 X_d (128, same encoding).   grads: as NeRF.
+constexpr RegionLayout siren_acts() { return {11, {8, 256, 256, 256, 256, 256, 256, 256, 256, 256, 128}}; }
 constexpr RegionLayout siren_grads() { return nerf_grads(); }
-// FilmSirenNeRF acts: 0 xin(8) | FiLM layer l=0..8 (input, hidden 0..6, rgb hidden): 1+2l X_l = sin(30 u),
-//                     2+2l C_l = 30 cos(30 u), u = gamma*A + beta (the linear output A is not kept: the FiLM table
-//                     gradient comes out of the per-image dW sums, see launch_field_backward).
+// FilmSirenNeRF acts: 0 xin(8) | FiLM layer l = 0..8 (input, hidden 0..6, rgb hidden): 1+l X_l = sin(30 u),
+//                     u = gamma*A + beta, encoded like SirenNeRF's (the linear output A is not kept either: the FiLM
+//                     table gradient comes out of the per-image dW sums, see launch_field_backward).
 // grads: 0..8 dL/du_l (256) | 9 head pre-act grads (4)
 constexpr RegionLayout film_acts() {
-    RegionLayout L{19, {}};
+    RegionLayout L{10, {}};
     L.width[0] = 8;
-    for (int i = 1; i < 19; ++i) L.width[i] = 256;
+    for (int i = 1; i < 10; ++i) L.width[i] = 256;
     return L;
 }
 constexpr RegionLayout film_grads() { return {10, {256, 256, 256, 256, 256, 256, 256, 256, 256, 4}}; }

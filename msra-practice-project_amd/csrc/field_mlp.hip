@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     constexpr RegionLayout RL = TINY ? tiny_acts() : nerf_acts();
     const int64_t SP = a.save_points;
     const auto rows = [&](int off_floats_per_point, int width) {
-        return SaveRows{SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, nullptr, width, pt.p, pt.valid};
+        return SaveRows{SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, width, pt.p, pt.valid};
     };
     if constexpr (SAVE) {
         f32x16 tmp[8];
@@ -230,15 +230,15 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     constexpr RegionLayout RL = siren_acts();
     const int64_t SP = a.save_points;
     const auto region = [&](int idx) { return a.save + (int64_t)region_offset(RL, idx) * SP; };
-    // sin layer l (1..8): X_l -> region 2l-1, C_l -> region 2l
+    // sin layer l (1..8): X_l (cosine sign in the lowest bit) -> region l
     const auto sin_rows = [&](int l) {
-        float* base = SAVE ? a.save + (int64_t)(8 + 512 * (l - 1)) * SP : nullptr;
-        return SaveRows{base, SAVE ? base + 256 * SP : nullptr, 256, pt.p, pt.valid};
+        return SaveRows{SAVE ? a.save + (int64_t)(8 + 256 * (l - 1)) * SP : nullptr, 256, pt.p, pt.valid};
     };
+    const SaveRows none{nullptr, 0, 0, false};
     const auto sin_act = [&](int l) {
         if constexpr (SAVE)
-            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, smem + kLdsAux0, a.save + (int64_t)(8 + 512 * (l - 1)) * SP,
-                                         a.save + (int64_t)(8 + 512 * (l - 1) + 256) * SP, 256, pt.p, pt.valid);
+            activate_train<8, ACT_SIN30>(acc, X, nullptr, c.h, smem + kLdsAux0, a.save + (int64_t)(8 + 256 * (l - 1)) * SP, 256,
+                                         pt.p, pt.valid);
         else
             activate<8, ACT_SIN30>(acc, X, nullptr, c.h, smem + kLdsAux0);
     };
@@ -255,32 +255,31 @@ __global__ __launch_bounds__(256, 1) void siren_fwd_kernel(MlpArgs a) {
     issue_first_stage<1, 32, false>(c, 1, 0, 0);
     init_acc<8, true>(smem + kLdsAux0, c.h, 1, pt.px, pt.py, pt.pz, acc);
     sin_act(1); slot ^= 1;
+    // sin layers store their own (encoded) rows from the activation hook: nothing is deferred to the next layer
 #pragma unroll 1
     for (int l = 1; l <= 3; ++l) {
-        SaveRows prev = sin_rows(l);
-        if (l == 1) prev.x = nullptr;                      // X_1 was stored by the K = 3 layer's own epilogue
-        fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(l + 1), prev);
+        fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE, false, 0>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(l + 1), none);
         slot ^= 1;
     }
-    fwd_layer<8, 8, false, 4, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(5), sin_rows(4));  // layers_pos[4]
+    fwd_layer<8, 8, false, 4, 32, false, ACT_SIN30, SAVE, false, 0>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(5), none);  // layers_pos[4]
     slot ^= 1;
-    fwd_layer<8, 8, true, 1, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc, X, nullptr, sin_rows(6), sin_rows(5));  // [5]: [pos | h]
+    fwd_layer<8, 8, true, 1, 32, false, ACT_SIN30, SAVE, false, 0>(c, slot, 0, 1, pt.px, pt.py, pt.pz, sel_x, acc, X, nullptr, sin_rows(6), none);  // [5]: [pos | h]
     slot ^= 1;
-    fwd_layer<8, 8, false, 3, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(7), sin_rows(6));  // [6]
+    fwd_layer<8, 8, false, 3, 32, false, ACT_SIN30, SAVE, false, 0>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(7), none);  // [6]
     slot ^= 1;
-    fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(8), sin_rows(7));  // [7] + sigma head
+    fwd_layer<8, 8, false, 1, 32, false, ACT_SIN30, SAVE, false, 0>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, sin_rows(8), none);  // [7] + sigma head
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
         sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
     }
     slot ^= 1;
-    const SaveRows g_rows{SAVE ? region(17) : nullptr, nullptr, 256, pt.p, pt.valid};
-    fwd_layer<8, 8, false, 8, 16, false, ACT_LINEAR, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, g_rows,
-                                                                    sin_rows(8));  // layers_dir[0] linear: G
+    const SaveRows g_rows{SAVE ? region(9) : nullptr, 256, pt.p, pt.valid};
+    fwd_layer<8, 8, false, 8, 16, false, ACT_LINEAR, SAVE, true, 0>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr, g_rows,
+                                                                    none);  // layers_dir[0] linear: G (stored by the next layer)
     slot ^= 1;
     fwd_layer<8, 4, true, 0, 0, false, ACT_SIN30, SAVE, false, 8>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, nullptr,
-                                                                  SaveRows{SAVE ? region(18) : nullptr, SAVE ? region(19) : nullptr, 128, pt.p, pt.valid},
+                                                                  SaveRows{SAVE ? region(10) : nullptr, 128, pt.p, pt.valid},
                                                                   g_rows);  // layers_dir[1]: [h | dir]; G from X
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     const float r = sigmoidf(head_dot<4>(X, aux, 4, c.h) + aux[7 * kPiece + 0]);
@@ -307,18 +306,17 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto film_row = [&](int s) { return smem + kLdsFilm0 + s * kFilmRow; };
     const int64_t SP = a.save_points;
-    // FiLM layer l (0..8): X_l -> region 1+2l, C_l -> 2+2l (each 256 wide, after the 8-wide xin)
+    // FiLM layer l (0..8): X_l (cosine sign in the lowest bit) -> region 1+l (256 wide, after the 8-wide xin)
     const auto film_rows = [&](int l) {
-        float* base = SAVE ? a.save + (int64_t)(8 + 512 * l) * SP : nullptr;
-        return SaveRows{base, SAVE ? base + 256 * SP : nullptr, 256, pt.p, pt.valid};
+        return SaveRows{SAVE ? a.save + (int64_t)(8 + 256 * l) * SP : nullptr, 256, pt.p, pt.valid};
     };
+    const SaveRows none{nullptr, 0, 0, false};
     const auto film_act = [&](int l, int slot_) {
-        if constexpr (SAVE) {
-            float* base = a.save + (int64_t)(8 + 512 * l) * SP;
-            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0, base, base + 256 * SP, 256, pt.p, pt.valid);
-        } else {
+        if constexpr (SAVE)
+            activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0, a.save + (int64_t)(8 + 256 * l) * SP, 256,
+                                        pt.p, pt.valid);
+        else
             activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0);
-        }
     };
     if constexpr (SAVE) {
         if (pt.valid && c.h == 0) {
@@ -335,21 +333,19 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     film_act(0, 0); slot ^= 1;
 #pragma unroll 1
     for (int l = 1; l <= 5; ++l) {                                                   // hidden_layers[0..4]
-        SaveRows prev = film_rows(l - 1);
-        if (l == 1) prev.x = nullptr;                      // X_0 was stored by the input layer's own epilogue
-        fwd_layer<8, 8, false, 1, 32, true, ACT_FILM, SAVE, true, 8>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(l), prev);
+        fwd_layer<8, 8, false, 1, 32, true, ACT_FILM, SAVE, false, 0>(c, slot, l + 1, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(l), none);
         slot ^= 1;
     }
-    fwd_layer<8, 8, false, 3, 32, true, ACT_FILM, SAVE, true, 8>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(6), film_rows(5));  // hidden_layers[5]
+    fwd_layer<8, 8, false, 3, 32, true, ACT_FILM, SAVE, false, 0>(c, slot, 7, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(6), none);  // hidden_layers[5]
     slot ^= 1;
-    fwd_layer<8, 8, false, USE_DIR ? 8 : 5, 32, true, ACT_FILM, SAVE, true, 8>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(7), film_rows(6));  // hidden_layers[6]
+    fwd_layer<8, 8, false, USE_DIR ? 8 : 5, 32, true, ACT_FILM, SAVE, false, 0>(c, slot, 8, 0, 0.f, 0.f, 0.f, sel_x, acc, X, film_row(slot), film_rows(7), none);  // hidden_layers[6]
     float sigma;
     {
         const float* aux = smem + kLdsAux0 + slot * kLdsAux;
         sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
     }
     slot ^= 1;
-    fwd_layer<8, 8, USE_DIR, 0, 0, false, ACT_FILM, SAVE, false, 8>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, film_row(slot), film_rows(8), film_rows(7));   // hidden_layer_rgb
+    fwd_layer<8, 8, USE_DIR, 0, 0, false, ACT_FILM, SAVE, false, 0>(c, slot, 0, 1, pt.dx, pt.dy, pt.dz, sel_x, acc, X, film_row(slot), film_rows(8), none);   // hidden_layer_rgb
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;
     constexpr int hp = USE_DIR ? 4 : 1;
     const float r = sigmoidf(head_dot<8>(X, aux, hp + 0, c.h) + aux[(hp + 3) * kPiece + 0]);

@@ -125,7 +125,10 @@ __device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 // B operands come from bsel; when the last K block reads X[j] with j < MB-1 pass a copy (post overwrites X[j]).
 enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2, EPI_FILM = 3 };
 
-// EPI_FILM: saved = C = 30 cos(30 u); writes dL/du = dX (.) C rows and leaves dA = gamma (.) dL/du in X; gamma is
+// EPI_SIN / EPI_FILM: saved = the layer's X rows with the cosine's sign in the lowest mantissa bit; the derivative
+// factor C = 30 cos(30 u) is rebuilt from them (mi_math.h:dsin30_from_saved) one K block after the quarter's load
+// was issued, in the same mid slot that issues the load of the quarter eight further on.
+// EPI_FILM: writes dL/du = dX (.) C rows and leaves dA = gamma (.) dL/du in X; gamma is
 // this layer's FiLM row in LDS (`film_row`).  FILM layers also DMA the next epilogue's FiLM row (`next_film_layer`)
 // into the other film slot; `issue_slot` is the slot pair index handed to the stage issue (its aux / film
 // target is issue_slot ^ 1), `aux_slot` the slot the SCALED start row is read from.
@@ -160,8 +163,13 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             acc[m][4 * rg + 0] = 0.f; acc[m][4 * rg + 1] = 0.f; acc[m][4 * rg + 2] = 0.f; acc[m][4 * rg + 3] = 0.f;
         }
     };
+    static_assert(!(EPI == EPI_SIN || EPI == EPI_FILM) || KB >= 5, "sin rows are decoded one K block after their load");
     const auto mid = [&](auto kbc, auto sc) {
         constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
+        if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 1 && kb < 5 && slot < 16 && (slot & 1) == 0 && j - 8 < MB * 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[j - 8][q] = dsin30_from_saved(sv[j - 8][q]);
+        }
         if constexpr (kb < 4 && slot < 16) {
             if constexpr ((slot & 1) == 0) {
                 if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
@@ -270,20 +278,20 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     }
 }
 
-// dA = dX (.) C with C = 30 cos(30 A) saved by the training forward; stores dA rows, leaves them in X.
+// dA = dX (.) C with C = 30 cos(30 A) rebuilt from the saved (sign-encoded) X rows; stores dA rows, leaves them in X.
 template <int MB>
-__device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ C,
+__device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ Xs,
                                               float* __restrict__ dA, int64_t ld, int64_t p, bool valid, int h) {
-    const f32x4* crow = reinterpret_cast<const f32x4*>(C + p * ld + 4 * h);
+    const f32x4* crow = reinterpret_cast<const f32x4*>(Xs + p * ld + 4 * h);
     f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 cv = crow[m * 8 + rg * 2];
+            const f32x4 xv = crow[m * 8 + rg * 2];
             f32x4 o;
-            o.x = cv.x * dX[m][4 * rg + 0]; o.y = cv.y * dX[m][4 * rg + 1];
-            o.z = cv.z * dX[m][4 * rg + 2]; o.w = cv.w * dX[m][4 * rg + 3];
+            o.x = dsin30_from_saved(xv.x) * dX[m][4 * rg + 0]; o.y = dsin30_from_saved(xv.y) * dX[m][4 * rg + 1];
+            o.z = dsin30_from_saved(xv.z) * dX[m][4 * rg + 2]; o.w = dsin30_from_saved(xv.w) * dX[m][4 * rg + 3];
             X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
             if (valid) drow[m * 8 + rg * 2] = o;
         }
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    sin_bwd_store<4>(acc, X, acts(19), grads(9), 128, p, valid, c.h);                          // dA layers_dir.1
+    sin_bwd_store<4>(acc, X, acts(10), grads(9), 128, p, valid, c.h);                          // dA layers_dir.1 (X_d rows)
     int slot = 0;
     {   // layers_dir.1^T (h part); layers_dir.0 is linear: dA = dG.  B operand copied (see nerf_bwd_kernel).
         f32x16 Bd[4];
@@ -339,14 +347,14 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
         bwd_layer<4, 8, 1, 32, EPI_LINEAR, false, false, true, 0>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
     }
     slot ^= 1;
-    // layers_dir.0^T + sigma head; dA7 = dX8 (.) C8
-    bwd_layer<8, 8, 0, 32, EPI_SIN, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, acts(16), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
+    // layers_dir.0^T + sigma head; dA7 = dX8 (.) C8, C_l rebuilt from the saved X_l rows (acts region l)
+    bwd_layer<8, 8, 0, 32, EPI_SIN, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, acts(8), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
 #pragma unroll 1
     for (int l = 7; l >= 2; --l)                                                                // L7^T .. L2^T: dA_{l-1} = dX_l (.) C_l
-        bwd_layer<8, 8, 0, 32, EPI_SIN, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(8 + 512 * (l - 1) + 256) * P,
+        bwd_layer<8, 8, 0, 32, EPI_SIN, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(8 + 256 * (l - 1)) * P,
                                                                a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, -1, 0, nullptr,
                                                                a.grads + (int64_t)(256 * l) * P, 256);
-    bwd_layer<8, 8, 0, 0, EPI_SIN, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T: dA0 = dX1 (.) C1
+    bwd_layer<8, 8, 0, 0, EPI_SIN, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T: dA0 = dX1 (.) C1
 }
 
 // =========================================================================================
@@ -357,10 +365,10 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
 // the linear output A nor any cross-lane reduction.
 // =========================================================================================
 template <int MB>
-__device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ C,
+__device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ Xs,
                                                const float* film_row, float* __restrict__ dU, int64_t p, bool valid,
                                                int h) {
-    const f32x4* crow = reinterpret_cast<const f32x4*>(C + p * 256 + 4 * h);
+    const f32x4* crow = reinterpret_cast<const f32x4*>(Xs + p * 256 + 4 * h);
     const lds4_t pg = lds_base(film_row + h * 4);
     f32x4* drow = reinterpret_cast<f32x4*>(dU + p * 256 + 4 * h);
 #pragma unroll
@@ -371,7 +379,7 @@ __device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
             f32x4 du;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                du[q] = cv[q] * dX[m][4 * rg + q];
+                du[q] = dsin30_from_saved(cv[q]) * dX[m][4 * rg + q];
                 X[m][4 * rg + q] = du[q] * gv[q];
             }
             if (valid) drow[m * 8 + rg * 2] = du;
@@ -381,7 +389,8 @@ __device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 // One FiLM chain layer (bwd_layer's EPI_FILM case) whose dL/du rows do not burst out of the last row either: FiLM
 // layers carry gamma (.) dL/du in X, so X cannot be stored later as dA can; instead the epilogue parks each dL/du
 // quarter in the register that held its C quarter (`ring`, owned by the kernel), and the NEXT layer's mid slot
-// 2(j%8) of K block j/8 stores it right before loading its own C quarter into the same register.
+// 2(j%8) of K block j/8 stores it right before loading its own saved-X quarter into the same register (decoded to
+// C = 30 cos(30 u) one K block later, see bwd_layer).
 //   STORE_PREV: ring holds the previous layer's dL/du (-> prev_dU);  KEEP: leave this layer's dL/du in ring
 //   (the caller's next layer stores it) instead of storing it from the epilogue.
 template <int NEXT_BLOCK, bool SCALED, bool FILM_NEXT, bool STORE_PREV, bool KEEP, class BSel>
@@ -406,6 +415,10 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSe
     };
     const auto mid = [&](auto kbc, auto sc) {
         constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
+        if constexpr (kb >= 1 && kb < 5 && slot < 16 && (slot & 1) == 0) {       // the quarter loaded one K block ago
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ring[j - 8][q] = dsin30_from_saved(ring[j - 8][q]);
+        }
         if constexpr (kb < 4 && slot < 16 && (slot & 1) == 0) {
             constexpr int idx = (j / 4) * 8 + (j % 4) * 2;
             if constexpr (STORE_PREV) { if (valid) prow[idx] = ring[j]; }
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     f32x16 X[8], acc[8];
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto film_row = [&](int slot) { return smem + kLdsFilm0 + slot * kFilmRow; };
-    const auto C = [&](int l) { return a.acts + (int64_t)(8 + 512 * l + 256) * P; };
+    const auto C = [&](int l) { return a.acts + (int64_t)(8 + 256 * l) * P; };    // saved X_l rows: C_l is rebuilt from them
     const auto dU = [&](int l) { return a.grads + (int64_t)(256 * l) * P; };
 
     __syncthreads();
@@ -531,10 +544,23 @@ __global__ __launch_bounds__(256) void film_finish_kernel(const float* __restric
 // (conflict-free: 16 consecutive lanes read 16 consecutive float4) per operand and point pair.
 constexpr int kGemmStagePts = 32;
 
+// Up to kMaxGemmJobs GEMMs of one tile shape in ONE launch (grid.y = job): every job contracts the same P points, so
+// a training step's nine 256x256 weight gradients are one launch of 9 x slabs workgroups instead of nine launches
+// of `slabs` - at the 1024-ray batch of nerf/train_nerf.py the step is launch-bound otherwise.
+constexpr int kMaxGemmJobs = 12;
+struct GemmBatch {
+    const float* dA[kMaxGemmJobs];
+    const float* X[kMaxGemmJobs];
+    float* partial[kMaxGemmJobs];      // records (slab*KS + ks) of TM*TK (+ TM bias sums) floats
+    int with_bias[kMaxGemmJobs];
+};
+
 template <int CB, int WM, int WK>
-__global__ __launch_bounds__(256, 1) void dw_gemm_kernel(const float* __restrict__ dA, const float* __restrict__ X,
-                                                             int64_t P, int slab_pts, float* __restrict__ partial,
-                                                             int with_bias) {
+__global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t P, int slab_pts) {
+    const float* __restrict__ dA = jobs.dA[blockIdx.y];
+    const float* __restrict__ X = jobs.X[blockIdx.y];
+    float* __restrict__ partial = jobs.partial[blockIdx.y];
+    const int with_bias = jobs.with_bias[blockIdx.y];
     constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK, T = kGemmStagePts;
     constexpr int PA = T * TM / 256, PB = T * TK / 256;              // 1 KiB pieces per stage and operand
     constexpr int NPW = (PA + PB + 3) / 4;                           // pieces per wave and stage
@@ -676,11 +702,20 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int n_
 // Thin gradients: out[c][f] = sum_p S[p][c0+c] * H[p][f] for c < nc <= 3, f < F <= 256, plus sum_p S[p][c0+c].
 //   heads:        S = head pre-activation grads [P,4], H = the head's input  -> dW_head[c][f], db_head[c]
 //   K = 3 inputs: S = xin [P,8] (xyz | dir),           H = dA of the layer   -> dW[f][col0 + c]
-// grid = point slabs, block = 256 threads = features; partial[slab][4][256], bias_partial[slab][4].
-__global__ __launch_bounds__(256) void thin_grad_kernel(const float* __restrict__ S, int lds_, int c0, int nc,
-                                                        const float* __restrict__ H, int ldh, int F, int64_t P,
-                                                        int slab_pts, float* __restrict__ partial,
-                                                        float* __restrict__ bias_partial) {
+// grid = (point slabs, jobs), block = 256 threads = features; partial[slab][4][256], bias_partial[slab][4] per job.
+constexpr int kMaxThinJobs = 6;
+struct ThinBatch {
+    const float* S[kMaxThinJobs]; const float* H[kMaxThinJobs];
+    float* partial[kMaxThinJobs]; float* bias_partial[kMaxThinJobs];
+    int lds_[kMaxThinJobs], c0[kMaxThinJobs], nc[kMaxThinJobs], ldh[kMaxThinJobs], F[kMaxThinJobs];
+};
+__global__ __launch_bounds__(256) void thin_grad_kernel(ThinBatch tb, int64_t P, int slab_pts) {
+    const int job = blockIdx.y;
+    const float* __restrict__ S = tb.S[job];
+    const float* __restrict__ H = tb.H[job];
+    float* __restrict__ partial = tb.partial[job];
+    float* __restrict__ bias_partial = tb.bias_partial[job];
+    const int lds_ = tb.lds_[job], c0 = tb.c0[job], nc = tb.nc[job], ldh = tb.ldh[job], F = tb.F[job];
     // wave w takes points p0 + w, p0 + w + 4, ...; lane l the features 4l..4l+3 (float4 rows, 4 points in flight);
     // the four waves' sums are added in wave order at the end, so the result does not depend on timing
     __shared__ float red[4][4][256];
@@ -737,6 +772,47 @@ __global__ void reduce_columns_kernel(const float* __restrict__ partial, int n, 
     }
 }
 
+// Every cross-slab reduction of a backward pass in ONE launch (grid.y = job), fixed order, deterministic.  A job sums
+// n records of `rec` floats element-wise; element idx < TM*TK is tile entry (row, col) = (idx / TK, idx % TK), the
+// tail (when bias_dst) the TM bias sums.  Placement: dst[row*ld + col0 + col], or transposed (K = 3 weight columns:
+// record [c][f] -> dst[f*ld + col0 + c]).
+constexpr int kMaxReduceJobs = 24;
+struct ReduceJob {
+    const float* src;
+    float* dst;
+    float* bias_dst;
+    int n, rec, TM, TK, ld, col0, rows_valid, cols_valid, transposed;
+};
+struct ReduceBatch { ReduceJob job[kMaxReduceJobs]; };
+
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceBatch rb) {
+    // four consecutive record entries per thread (every record length and tile width is a multiple of 4): 16-byte
+    // loads, four partials in flight; the final sum order is fixed whatever the timing
+    const ReduceJob& j = rb.job[blockIdx.y];
+    const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (idx >= j.rec) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(j.src + idx);
+    const int64_t stride4 = j.rec / 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int k = 0;
+    for (; k + 4 <= j.n; k += 4) {
+        s0 += p[(int64_t)k * stride4]; s1 += p[(int64_t)(k + 1) * stride4];
+        s2 += p[(int64_t)(k + 2) * stride4]; s3 += p[(int64_t)(k + 3) * stride4];
+    }
+    for (; k < j.n; ++k) s0 += p[(int64_t)k * stride4];
+    const f32x4 s = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = idx + q;
+        const bool is_bias = e >= j.TM * j.TK;
+        const int row = is_bias ? e - j.TM * j.TK : e / j.TK, col = is_bias ? 0 : e % j.TK;
+        if (row >= j.rows_valid || (!is_bias && col >= j.cols_valid) || (is_bias && !j.bias_dst)) continue;
+        if (is_bias) j.bias_dst[row] = s[q];
+        else if (j.transposed) j.dst[(int64_t)col * j.ld + j.col0 + row] = s[q];
+        else j.dst[(int64_t)row * j.ld + j.col0 + col] = s[q];
+    }
+}
+
 // ---- host orchestration ---------------------------------------------------------------------
 int launch_pack_bwd(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream) {
     const PackTable* t = host_table_bwd(kind);
@@ -775,12 +851,18 @@ static int slab_points(int64_t P) {
     if (s < 256) s = 256;
     return (int)s;
 }
+static int64_t batched_partial_floats(int kind, int64_t P);
 int64_t bwd_partial_floats(int64_t P) {
     const int slab = slab_points(P);
     const int64_t slabs = (P + slab - 1) / slab;
     const int64_t tiles = slabs * 4;                                   // up to 4 k-split partial tiles per slab
     const int64_t groups = (tiles + kReduceGroup - 1) / kReduceGroup;
-    return (tiles + groups) * (256 * 256 + 256) + 1024;                // partial records (tile + bias sums) + level-1 sums
+    int64_t most = (tiles + groups) * (256 * 256 + 256) + 1024;        // FiLM kinds: one GEMM at a time (records + level-1 sums)
+    for (int kind : {0, 1, 4}) {                                       // the others: every job of the pass at once
+        const int64_t n = batched_partial_floats(kind, P);
+        if (n > most) most = n;
+    }
+    return most;
 }
 
 // Sum `n` partial tiles of TM x TK (at `partial`, level-1 scratch at `tmp`) into dst.
@@ -823,7 +905,9 @@ static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P
         return 0;
     });
     if (arc) return arc;
-    hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), lds, stream, dA, X, P, slab, partial, gb ? 1 : 0);
+    GemmBatch one{};
+    one.dA[0] = dA; one.X[0] = X; one.partial[0] = partial; one.with_bias[0] = gb ? 1 : 0;
+    hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), lds, stream, one, P, slab);
     const float* src = partial;
     int m = n;
     if (m > kReduceGroup) {
@@ -843,8 +927,10 @@ static int run_head(const float* dpre, int c0, int nc, const float* H, int ldh, 
     const int slabs = (int)((P + slab - 1) / slab);
     float* tmp = partial + (int64_t)slabs * 4 * 256;
     float* bias_partial = tmp + (int64_t)((slabs + kReduceGroup - 1) / kReduceGroup) * 4 * 256;
-    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, dpre, 4, c0, nc, H, ldh, F, P, slab, partial,
-                       bias_partial);
+    ThinBatch one{};
+    one.S[0] = dpre; one.lds_[0] = 4; one.c0[0] = c0; one.nc[0] = nc; one.H[0] = H; one.ldh[0] = ldh; one.F[0] = F;
+    one.partial[0] = partial; one.bias_partial[0] = bias_partial;
+    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, one, P, slab);
     reduce_tiles(partial, slabs, 4, 256, tmp, gw, F, 0, nc, F, stream);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, bias_partial, slabs, 1, 4, gb, 4, 0, 1, nc);
     return check_launch("head_grad");
@@ -891,8 +977,10 @@ static int run_k3(const float* xin, int c0, const float* dA, int lda, int F, int
     const int slabs = (int)((P + slab - 1) / slab);
     float* tmp = partial + (int64_t)slabs * 4 * 256;
     float* bias_partial = tmp + (int64_t)((slabs + kReduceGroup - 1) / kReduceGroup) * 4 * 256;
-    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, xin, 8, c0, 3, dA, lda, F, P, slab, partial,
-                       bias_partial);
+    ThinBatch one{};
+    one.S[0] = xin; one.lds_[0] = 8; one.c0[0] = c0; one.nc[0] = 3; one.H[0] = dA; one.ldh[0] = lda; one.F[0] = F;
+    one.partial[0] = partial; one.bias_partial[0] = bias_partial;
+    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, one, P, slab);
     const float* src = partial;
     int n = slabs;
     if (n > kReduceGroup) {
@@ -902,6 +990,172 @@ static int run_k3(const float* xin, int c0, const float* dA, int lda, int F, int
     }
     hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(256), 0, stream, src, n, 3, F, gw, w_ld, w_col0);
     return check_launch("k3_grad");
+}
+
+// ---- batched orchestration (NeRF, TinyNeRF, SirenNeRF) -----------------------------------------------------------
+// A backward pass is: the chain kernel, then every weight-gradient GEMM of one tile shape in ONE launch (grid.y =
+// job), the thin (1-/3-row) gradients in one launch, and ONE reduction launch that sums every job's slab partials
+// into the gradient tensors - 8 launches for a NeRF (it was 41: at the 1024-ray batch of nerf/train_nerf.py the step
+// is launch-bound).  With several jobs per launch a job needs fewer slabs to fill the chip (slabs x jobs ~ 2 per
+// CU), so the partial tiles written and re-read shrink by the same factor.
+struct BwdBatcher {
+    int64_t P;
+    float* partial;            // scratch base (null: plan only - used to size the scratch)
+    int64_t used = 0;          // floats of scratch handed out
+    hipStream_t stream;
+    struct Group { GemmBatch b{}; int n = 0; ReduceJob red[kMaxGemmJobs]; } g422, g221, g412, g111;
+    ThinBatch thin{};
+    int n_thin = 0;
+    ReduceJob thin_red[2 * kMaxThinJobs];
+    int n_thin_red = 0;
+    ReduceBatch all{};
+    int n_red = 0, max_rec = 0;
+
+    static int slabs_for(int64_t P, int njobs) {
+        // one workgroup per CU over the whole launch: the workgroups of a launch do equal work, so a single wave of
+        // them has no tail, and fewer slabs mean fewer partial tiles to write and to sum
+        int64_t s = (256 + njobs - 1) / njobs;
+        if (s > 256) s = 256;
+        const int64_t most = (P + 255) / 256;              // slabs of at least 256 points
+        if (s > most) s = most;
+        return (int)(s < 1 ? 1 : s);
+    }
+    static int slab_pts_for(int64_t P, int slabs) { return (int)(((P + slabs - 1) / slabs + 31) / 32 * 32); }
+
+    float* take(int64_t floats) {
+        float* p = partial ? partial + used : nullptr;
+        used += (floats + 255) / 256 * 256;
+        return p;
+    }
+    void add_reduce(const ReduceJob& j) {
+        all.job[n_red++] = j;
+        if (j.rec > max_rec) max_rec = j.rec;
+    }
+    // dW[M rows][w_ld] at column w_col0 (+ bias gradient gb) = dA^T X over the P points
+    template <int CB, int WM, int WK>
+    void gemm(Group& g, const float* dA, const float* X, float* gw, int w_ld, int w_col0, int rows_valid, int cols_valid,
+              float* gb) {
+        constexpr int TM = 128 * WM, TK = 32 * CB * WK;
+        g.b.dA[g.n] = dA; g.b.X[g.n] = X; g.b.with_bias[g.n] = gb ? 1 : 0;
+        g.red[g.n] = ReduceJob{nullptr, gw, gb, 0, TM * TK + (gb ? TM : 0), TM, TK, w_ld, w_col0, rows_valid, cols_valid, 0};
+        ++g.n;
+    }
+    template <int CB, int WM, int WK>
+    int flush(Group& g) {
+        if (!g.n) return 0;
+        constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
+        const int slabs = slabs_for(P, g.n), slab = slab_pts_for(P, slabs);
+        const int n_slabs = (int)((P + slab - 1) / slab);
+        for (int i = 0; i < g.n; ++i) {
+            g.red[i].n = n_slabs * KS;
+            g.b.partial[i] = take((int64_t)g.red[i].n * g.red[i].rec);
+            g.red[i].src = g.b.partial[i];
+            add_reduce(g.red[i]);
+        }
+        if (!partial) return 0;
+        constexpr size_t lds = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
+        static PerDeviceOnce attr_once;                                               // one per template instance
+        const int arc = attr_once.run([&]() {
+            if (hipFuncSetAttribute((const void*)dw_gemm_kernel<CB, WM, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) { set_error("hipFuncSetAttribute(dw_gemm) failed"); return -2; }
+            return 0;
+        });
+        if (arc) return arc;
+        hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(n_slabs, g.n), dim3(256), lds, stream, g.b, P, slab);
+        return check_launch("dw_gemm (batched)");
+    }
+    // out[c][f] = sum_p S[p][c0+c] H[p][f]: heads (dst [nc][F], bias gb[nc]) or K = 3 weight columns (transposed into
+    // dst[f*ld + col0 + c], no bias)
+    void thin_job(const float* S, int lds_, int c0, int nc, const float* H, int ldh, int F, float* dst, int ld, int col0,
+                  bool transposed, float* gb) {
+        const int i = n_thin++;
+        thin.S[i] = S; thin.lds_[i] = lds_; thin.c0[i] = c0; thin.nc[i] = nc; thin.H[i] = H; thin.ldh[i] = ldh; thin.F[i] = F;
+        // record [4][256]: row c, col f
+        thin_red[n_thin_red++] = transposed ? ReduceJob{nullptr, dst, nullptr, 0, 1024, 4, 256, ld, col0, nc, F, 1}
+                                            : ReduceJob{nullptr, dst, nullptr, 0, 1024, 4, 256, F, 0, nc, F, 0};
+        if (gb) thin_red[n_thin_red++] = ReduceJob{nullptr, gb, nullptr, 0, 4, 1, 4, 4, 0, 1, nc, 0};
+        else thin_red[n_thin_red++] = ReduceJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    int flush_thin() {
+        if (!n_thin) return 0;
+        const int slabs = slabs_for(P, n_thin), slab = slab_pts_for(P, slabs);
+        const int n_slabs = (int)((P + slab - 1) / slab);
+        for (int i = 0; i < n_thin; ++i) {
+            thin.partial[i] = take((int64_t)n_slabs * 1024);
+            thin.bias_partial[i] = take((int64_t)n_slabs * 4);
+            ReduceJob a = thin_red[2 * i], b = thin_red[2 * i + 1];
+            a.n = n_slabs; a.src = thin.partial[i];
+            add_reduce(a);
+            if (b.dst) { b.n = n_slabs; b.src = thin.bias_partial[i]; add_reduce(b); }
+        }
+        if (!partial) return 0;
+        hipLaunchKernelGGL(thin_grad_kernel, dim3(n_slabs, n_thin), dim3(256), 0, stream, thin, P, slab);
+        return check_launch("thin_grad (batched)");
+    }
+    // gb[f] = sum_p dA[p][f] (bias of a layer whose weights are all K = 3 columns)
+    int colsum(const float* dA, int lda, int F, float* gb) {
+        const int slabs = slabs_for(P, 1), slab = slab_pts_for(P, slabs);
+        const int n_slabs = (int)((P + slab - 1) / slab);
+        float* part = take((int64_t)n_slabs * 256);
+        add_reduce(ReduceJob{part, gb, nullptr, n_slabs, 256, 1, 256, 256, 0, 1, F, 0});
+        if (!partial) return 0;
+        hipLaunchKernelGGL(colsum_kernel, dim3(n_slabs), dim3(256), 0, stream, dA, lda, F, P, slab, part);
+        return check_launch("colsum");
+    }
+    int reduce_all() {
+        if (!partial || !n_red) return 0;
+        hipLaunchKernelGGL(reduce_jobs_kernel, dim3((max_rec / 4 + 255) / 256, n_red), dim3(256), 0, stream, all);
+        return check_launch("reduce_jobs");
+    }
+};
+
+// The jobs of one backward pass, per kind.  partial == nullptr: plan only (b.used = scratch floats needed).
+static int batched_backward(int kind, BwdBatcher& b, const float* acts, float* grads, float* const* gp) {
+    const int64_t P = b.P;
+    int rc;
+    if (kind == 0 || kind == 4) {
+        const bool tiny = kind == 4;
+        const RegionLayout AL = tiny ? tiny_acts() : nerf_acts(), GL = tiny ? tiny_grads() : nerf_grads();
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
+        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
+        b.gemm<2, 2, 1>(b.g221, G(0), A(0), gp[0], 60, 0, 256, 60, gp[1]);                        // layers_pos.0: dA0 x E_pos
+        if (!tiny) {
+            for (int l = 1; l <= 7; ++l)
+                b.gemm<4, 2, 2>(b.g422, G(l), A(l), gp[2 * l], l == 5 ? 316 : 256, l == 5 ? 60 : 0, 256, 256, gp[2 * l + 1]);
+            b.gemm<2, 2, 1>(b.g221, G(5), A(0), gp[10], 316, 0, 256, 60, nullptr);                // skip layer's E_pos columns
+            b.gemm<4, 2, 2>(b.g422, G(8), A(8), gp[16], 256, 0, 256, 256, gp[17]);                // layers_dir.0 x H8
+            b.gemm<4, 1, 2>(b.g412, G(9), A(9), gp[18], 280, 0, 128, 256, gp[19]);                // layers_dir.1 x [G |
+            b.gemm<1, 1, 1>(b.g111, G(9), A(10), gp[18], 280, 256, 128, 24, nullptr);             //                E_dir]
+            b.thin_job(G(10), 4, 3, 1, A(8), 256, 256, gp[20], 256, 0, false, gp[21]);            // sigma head x H8
+            b.thin_job(G(10), 4, 0, 3, A(11), 128, 128, gp[22], 128, 0, false, gp[23]);           // rgb head x H_d
+        } else {
+            for (int l = 1; l <= 3; ++l) b.gemm<4, 2, 2>(b.g422, G(l), A(l), gp[2 * l], 256, 0, 256, 256, gp[2 * l + 1]);
+            b.gemm<4, 1, 2>(b.g412, G(4), A(4), gp[8], 280, 0, 128, 256, gp[9]);
+            b.gemm<1, 1, 1>(b.g111, G(4), A(5), gp[8], 280, 256, 128, 24, nullptr);
+            b.thin_job(G(5), 4, 3, 1, A(4), 256, 256, gp[10], 256, 0, false, gp[11]);
+            b.thin_job(G(5), 4, 0, 3, A(6), 128, 128, gp[12], 128, 0, false, gp[13]);
+        }
+    } else {                                                                                      // SirenNeRF
+        const RegionLayout AL = siren_acts(), GL = siren_grads();
+        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
+        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
+        for (int l = 1; l <= 7; ++l)                                                              // input of layer l: X_l
+            b.gemm<4, 2, 2>(b.g422, G(l), A(l), gp[2 * l], l == 5 ? 259 : 256, l == 5 ? 3 : 0, 256, 256, gp[2 * l + 1]);
+        b.gemm<4, 2, 2>(b.g422, G(8), A(8), gp[16], 256, 0, 256, 256, gp[17]);                    // layers_dir.0 x X8
+        b.gemm<4, 1, 2>(b.g412, G(9), A(9), gp[18], 259, 0, 128, 256, gp[19]);                    // layers_dir.1 x G
+        b.thin_job(A(0), 8, 0, 3, G(0), 256, 256, gp[0], 3, 0, true, nullptr);                    // layers_pos.0 (K = 3)
+        b.thin_job(A(0), 8, 0, 3, G(5), 256, 256, gp[10], 259, 0, true, nullptr);                 // skip layer's xyz columns
+        b.thin_job(A(0), 8, 3, 3, G(9), 128, 128, gp[18], 259, 256, true, nullptr);               // layers_dir.1's dir columns
+        b.thin_job(G(10), 4, 3, 1, A(8), 256, 256, gp[20], 256, 0, false, gp[21]);                // sigma head x X8
+        b.thin_job(G(10), 4, 0, 3, A(10), 128, 128, gp[22], 128, 0, false, gp[23]);               // rgb head x X_d
+        if ((rc = b.colsum(G(0), 256, 256, gp[1]))) return rc;                                    // bias of layers_pos.0
+    }
+    if ((rc = b.flush<4, 2, 2>(b.g422))) return rc;
+    if ((rc = b.flush<2, 2, 1>(b.g221))) return rc;
+    if ((rc = b.flush<4, 1, 2>(b.g412))) return rc;
+    if ((rc = b.flush<1, 1, 1>(b.g111))) return rc;
+    if ((rc = b.flush_thin())) return rc;
+    return b.reduce_all();
 }
 
 // Backward of a NeRF / TinyNeRF field over P points.  grad_params[2i], [2i+1]: device pointers to the weight /
@@ -930,47 +1184,13 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
     BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P, film, film_partial, points_per_group, tpg, n_groups * tpg};
     const unsigned blocks = (unsigned)((kind == 2 || kind == 3) ? n_groups * tpg : (P + 127) / 128);
     int rc;
-    if (kind == 0) {
-        hipLaunchKernelGGL(nerf_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
-        if ((rc = check_launch("nerf_bwd_kernel"))) return rc;
-        constexpr RegionLayout AL = nerf_acts(), GL = nerf_grads();
-        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
-        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
-        // layers_pos.0: dA0 x E_pos
-        if ((rc = run_gemm<2, 2, 1>(G(0), 256, A(0), 64, P, partial, gp[0], 60, 0, 256, 60, gp[1], stream))) return rc;
-        for (int l = 1; l <= 7; ++l) {
-            const int ldw = l == 5 ? 316 : 256, col0 = l == 5 ? 60 : 0;
-            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(l), 256, P, partial, gp[2 * l], ldw, col0, 256, 256, gp[2 * l + 1], stream))) return rc;
-        }
-        if ((rc = run_gemm<2, 2, 1>(G(5), 256, A(0), 64, P, partial, gp[10], 316, 0, 256, 60, nullptr, stream))) return rc;
-        // layers_dir.0: dA x H8 ; layers_dir.1: dA(128) x [G | E_dir]
-        if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(8), 256, P, partial, gp[16], 256, 0, 256, 256, gp[17], stream))) return rc;
-        if ((rc = run_gemm<4, 1, 2>(G(9), 128, A(9), 256, P, partial, gp[18], 280, 0, 128, 256, gp[19], stream))) return rc;
-        if ((rc = run_gemm<1, 1, 1>(G(9), 128, A(10), 32, P, partial, gp[18], 280, 256, 128, 24, nullptr, stream))) return rc;
-        // heads: sigma (row 3 of dpre) x H8, rgb (rows 0..2) x H_d
-        if ((rc = run_head(G(10), 3, 1, A(8), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
-        if ((rc = run_head(G(10), 0, 3, A(11), 128, 128, P, partial, gp[22], gp[23], stream))) return rc;
-    } else if (kind == 1) {
-        hipLaunchKernelGGL(siren_bwd_kernel, dim3(blocks), dim3(256), lds, stream, a);
-        if ((rc = check_launch("siren_bwd_kernel"))) return rc;
-        constexpr RegionLayout AL = siren_acts(), GL = siren_grads();
-        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
-        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
-        // layers_pos.0 (K = 3): dW = dA0^T xyz, bias = column sums of dA0 (taken by a K=... GEMM-free reduction)
-        if ((rc = run_k3(A(0), 0, G(0), 256, 256, P, partial, gp[0], 3, 0, stream))) return rc;
-        for (int l = 1; l <= 7; ++l) {           // input of layer l is X_l = acts region 2l-1
-            const int ldw = l == 5 ? 259 : 256, col0 = l == 5 ? 3 : 0;
-            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(2 * l - 1), 256, P, partial, gp[2 * l], ldw, col0, 256, 256, gp[2 * l + 1], stream))) return rc;
-        }
-        if ((rc = run_k3(A(0), 0, G(5), 256, 256, P, partial, gp[10], 259, 0, stream))) return rc;
-        // bias of layers_pos.0: ride on a (256 x 32) GEMM against the first saved block is wasteful; use the thin
-        // kernel with S = ones instead: column sums of dA0 = sum_p 1 * dA0[p][f]  -> computed by run_bias below
-        if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(15), 256, P, partial, gp[16], 256, 0, 256, 256, gp[17], stream))) return rc;   // layers_dir.0 x X8
-        if ((rc = run_gemm<4, 1, 2>(G(9), 128, A(17), 256, P, partial, gp[18], 259, 0, 128, 256, gp[19], stream))) return rc;   // layers_dir.1 x G
-        if ((rc = run_k3(A(0), 3, G(9), 128, 128, P, partial, gp[18], 259, 256, stream))) return rc;                             // ... x dir
-        if ((rc = run_head(G(10), 3, 1, A(15), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;                       // sigma x X8
-        if ((rc = run_head(G(10), 0, 3, A(18), 128, 128, P, partial, gp[22], gp[23], stream))) return rc;                       // rgb x X_d
-        if ((rc = run_colsum(G(0), 256, 256, P, partial, gp[1], stream))) return rc;                                            // bias layers_pos.0
+    if (kind == 0 || kind == 1 || kind == 4) {
+        if (kind == 0) hipLaunchKernelGGL(nerf_bwd_kernel<false>, dim3(blocks), dim3(256), lds, stream, a);
+        else if (kind == 4) hipLaunchKernelGGL(nerf_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL(siren_bwd_kernel, dim3(blocks), dim3(256), lds, stream, a);
+        if ((rc = check_launch("backward chain"))) return rc;
+        BwdBatcher bb{P, partial, 0, stream};
+        if ((rc = batched_backward(kind, bb, acts, grads, gp))) return rc;
     } else if (kind == 2 || kind == 3) {
         const bool use_dir = kind == 2;
         if (!film || !film_partial || !grad_film || !params) {
@@ -1003,13 +1223,13 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
             if ((rc = run_k3(A(0), 0, G(0), 256, 256, ppg, partial, T3, 3, 0, stream))) return rc;
             if ((rc = run_colsum(G(0), 256, 256, ppg, partial, sg, stream))) return rc;
             finish(T3, 3, 0, 0, 3, 0, 1);
-            // hidden_layers[l-1] (FiLM layer l, parameter pair l): input X_{l-1} = acts region 1 + 2(l-1)
+            // hidden_layers[l-1] (FiLM layer l, parameter pair l): input X_{l-1} = acts region l
             for (int l = 1; l <= 7; ++l) {
-                if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(1 + 2 * (l - 1)), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
+                if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(l), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
                 finish(T, 256, l, l, 256, 0, 1);
             }
             // hidden_layer_rgb (FiLM layer 8, parameter pair 9): [X_7 | dir]
-            if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(15), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
+            if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(8), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
             finish(T, 256, 8, 9, ld9, 0, 1);
             if (use_dir) {
                 if ((rc = run_k3(A(0), 3, G(8), 256, 256, ppg, partial, T3, 3, 0, stream))) return rc;
@@ -1020,23 +1240,17 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
         // heads: sigma (param pair 8) on X_7, rgb (pair 10) on X_8 - no FiLM in between, all images at once
         const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
         const float* dpre = grads + (int64_t)(9 * 256) * P;
-        if ((rc = run_head(dpre, 3, 1, A(15), 256, 256, P, partial, gp[16], gp[17], stream))) return rc;
-        if ((rc = run_head(dpre, 0, 3, A(17), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;
-    } else {
-        hipLaunchKernelGGL(nerf_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
-        if ((rc = check_launch("nerf_bwd_kernel"))) return rc;
-        constexpr RegionLayout AL = tiny_acts(), GL = tiny_grads();
-        const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
-        const auto G = [&](int r) { return grads + (int64_t)region_offset(GL, r) * P; };
-        if ((rc = run_gemm<2, 2, 1>(G(0), 256, A(0), 64, P, partial, gp[0], 60, 0, 256, 60, gp[1], stream))) return rc;
-        for (int l = 1; l <= 3; ++l)
-            if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(l), 256, P, partial, gp[2 * l], 256, 0, 256, 256, gp[2 * l + 1], stream))) return rc;
-        if ((rc = run_gemm<4, 1, 2>(G(4), 128, A(4), 256, P, partial, gp[8], 280, 0, 128, 256, gp[9], stream))) return rc;
-        if ((rc = run_gemm<1, 1, 1>(G(4), 128, A(5), 32, P, partial, gp[8], 280, 256, 128, 24, nullptr, stream))) return rc;
-        if ((rc = run_head(G(5), 3, 1, A(4), 256, 256, P, partial, gp[10], gp[11], stream))) return rc;
-        if ((rc = run_head(G(5), 0, 3, A(6), 128, 128, P, partial, gp[12], gp[13], stream))) return rc;
+        if ((rc = run_head(dpre, 3, 1, A(8), 256, 256, P, partial, gp[16], gp[17], stream))) return rc;      // sigma x X_7
+        if ((rc = run_head(dpre, 0, 3, A(9), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;      // rgb x X_8
     }
     return 0;
+}
+
+static int64_t batched_partial_floats(int kind, int64_t P) {
+    static float* const none[24] = {};
+    BwdBatcher bb{P, nullptr, 0, nullptr};
+    (void)batched_backward(kind, bb, nullptr, nullptr, none);
+    return bb.used + 1024;
 }
 
 }  // namespace mi

@@ -145,7 +145,13 @@ __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x
                 constexpr int m = decltype(mc)::value;
                 static_for<4>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], acc[m], 0, 0, 0);
+                    if constexpr (first_mm && q == 0 && (ORDER & 8)) {
+                        // the chain starts at zero: srcC = 0 is an inline constant, no accumulator to initialise
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], zero, 0, 0, 0);
+                    } else {
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], acc[m], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (first_mm && m + 1 < MB) pre(ic<m + 1>{}, qc);
                     if constexpr (last_mm) {
@@ -246,23 +252,22 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
     }
 }
 
-// Training flavour of the sin activations: besides X = sin(30 u) it stores, as [point][feature] rows, X and
-// the derivative factor C = 30 cos(30 u).
+// Training flavour of the sin activations: besides X = sin(30 u) it stores, as [point][feature] rows, X with the
+// sign of cos(30 u) in its lowest mantissa bit (mi_math.h:hw_sin30_saved) - all the backward needs of the layer.
 template <int MB, int ACT>
 __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
-                                               const float* aux, float* __restrict__ x_rows, float* __restrict__ c_rows,
-                                               int64_t ld, int64_t p, bool valid) {
+                                               const float* aux, float* __restrict__ x_rows, int64_t ld, int64_t p,
+                                               bool valid) {
     static_assert(ACT == ACT_SIN30 || ACT == ACT_FILM, "sin activations only");
     const lds4_t pb = lds_base(aux + h * 16);
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
     f32x4* xrow = reinterpret_cast<f32x4*>(x_rows + p * ld + 4 * h);
-    f32x4* crow = reinterpret_cast<f32x4*>(c_rows + p * ld + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            f32x4 g, b, xo, co;
+            f32x4 g, b, xo;
             const f32x4 bias = pb[m * 8 + rg];
             if constexpr (ACT == ACT_FILM) {
                 g = pf[m * 8 + rg * 2];
@@ -273,14 +278,11 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
                 const float v = __fadd_rn(acc[m][4 * rg + q], bias[q]);
                 float u = v;
                 if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), b[q]);
-                const SinCos sc = hw_sincos30(u);
+                const SinSaved sc = hw_sin30_saved(u);
                 X[m][4 * rg + q] = sc.s;
-                xo[q] = sc.s; co[q] = 30.f * sc.c;
+                xo[q] = sc.saved;
             }
-            if (valid) {
-                xrow[m * 8 + rg * 2] = xo;
-                crow[m * 8 + rg * 2] = co;
-            }
+            if (valid) xrow[m * 8 + rg * 2] = xo;
         }
     }
 }
@@ -294,8 +296,8 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 // two K blocks: NEXT_AUX, NEXT_BLOCK = pieces of one of its K blocks, 0 for none) are DMA'd into the other one.
 // HOOKS: pre(m, part) / post(m, part) are the sliced bias preload / activation of mma_chunk; without them
 // init(acc) runs as one lump before the first MFMA and the caller applies its epilogue after the call.
-template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, bool HOOKS = false, class Init,
-          class BSel, class Pre = NoHook, class Post = NoHook, class Mid = NoHook>
+template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, bool HOOKS = false, bool ZERO_START = false,
+          class Init, class BSel, class Pre = NoHook, class Post = NoHook, class Mid = NoHook>
 __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film_layer, Init init, BSel bsel,
                                              f32x16 (&acc)[8], Pre pre = Pre{}, Post post = Post{}, Mid mid = Mid{}) {
     static_assert(KB >= 2, "every MFMA layer has at least two K blocks");
@@ -305,7 +307,8 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
         constexpr bool two = kb0 + 1 < KB;
         constexpr int left = KB - 2 * (i + 1);                       // K blocks after this stage
         constexpr int next_blocks = left >= 2 ? 2 : (left > 0 ? left : 0);
-        constexpr int order0 = HOOKS ? ((kb0 == 0 ? 1 : 0) | (kb0 == KB - 1 ? 2 : 0)) : 0;
+        constexpr int zs = ZERO_START ? 8 : 0;         // ORDER bit 3: the layer's first MFMAs take srcC = 0
+        constexpr int order0 = HOOKS ? ((kb0 == 0 ? 1 | zs : 0) | (kb0 == KB - 1 ? 2 : 0)) : 0;
         constexpr int order1 = HOOKS ? (kb0 + 1 == KB - 1 ? 2 : 0) : 0;
         __syncthreads();
         if constexpr (i == 0 && !HOOKS) init(acc);
@@ -321,10 +324,16 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
     static_for<(KB + 1) / 2>(stage);
 }
 
-// Rows the training forward stores per layer (c may be null): X = activation, C = 30 cos(30 u) derivative
-// factor (sin nets); all [point][ld] row-major.
+// FiLM's gamma * A + beta (pi_GAN/modules.py:24): a rounded product, then a rounded sum, two elements at a time
+__device__ __forceinline__ f32x2 film_affine(f32x2 g, f32x2 v, f32x2 b) {
+#pragma clang fp contract(off)
+    return g * v + b;
+}
+
+// Rows the training forward stores per layer: X = the layer's activation, [point][ld] row-major (sin layers: with
+// the cosine's sign in the lowest mantissa bit, mi_math.h).
 struct SaveRows {
-    float* x; float* c;
+    float* x;
     int64_t ld, p;
     bool valid;
 };
@@ -334,31 +343,33 @@ struct SaveRows {
 // of X is rewritten only after every K block that reads it has been consumed).
 // Training stores do not burst either: with DEFER_X this layer's X rows are written by the NEXT layer's mid slots
 // (slot 2(j%8)+1 of K block j/8 for quarter j; X is that layer's B operand and unchanged until its last row) - that
-// layer receives them as `prev` (PREV_MB blocks).  The derivative factor C of the sin nets is not kept in
-// registers, so it is still stored by the activation hook.
+// layer receives them as `prev` (PREV_MB blocks).  Sin layers save an ENCODING of X (cosine sign in the lowest bit)
+// that is not what the registers carry on, so their rows are stored by the activation hook itself, one quarter per
+// hook.
 template <int KB, int MB, bool K3, int NEXT_AUX, int NEXT_BLOCK, bool FILM, int ACT, bool SAVE, bool DEFER_X = false,
           int PREV_MB = 0, class BSel>
 __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_layer, int k3_piece, float x, float y,
                                           float z, BSel bsel, f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row,
-                                          const SaveRows& sv, const SaveRows& prev = SaveRows{nullptr, nullptr, 0, 0, false}) {
+                                          const SaveRows& sv, const SaveRows& prev = SaveRows{nullptr, 0, 0, false}) {
     const int h = c.h;
     const lds4_t pb = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
     f32x4 bias_q[2], g_q[2], bb_q[2];
+    constexpr bool kSinAct = ACT == ACT_SIN30 || ACT == ACT_FILM;
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};              // the chain starts at zero; post adds the bias (see init_acc)
+        // The chain starts at zero and post adds the bias (see init_acc).  Plain layers need nothing here: their first
+        // MFMAs take srcC = 0 (mma_chunk ORDER bit 3).  K = 3 layers start from the three products.
         if constexpr (K3) {
             const f32x4 w0 = pb[(k3_piece + 0) * 64 + m * 8 + rg];
             const f32x4 w1 = pb[(k3_piece + 1) * 64 + m * 8 + rg];
             const f32x4 w2 = pb[(k3_piece + 2) * 64 + m * 8 + rg];
-            t.x = fmaf(w2.x, z, fmaf(w1.x, y, w0.x * x));
-            t.y = fmaf(w2.y, z, fmaf(w1.y, y, w0.y * x));
-            t.z = fmaf(w2.z, z, fmaf(w1.z, y, w0.z * x));
-            t.w = fmaf(w2.w, z, fmaf(w1.w, y, w0.w * x));
+            acc[m][4 * rg + 0] = fmaf(w2.x, z, fmaf(w1.x, y, w0.x * x));
+            acc[m][4 * rg + 1] = fmaf(w2.y, z, fmaf(w1.y, y, w0.y * x));
+            acc[m][4 * rg + 2] = fmaf(w2.z, z, fmaf(w1.z, y, w0.z * x));
+            acc[m][4 * rg + 3] = fmaf(w2.w, z, fmaf(w1.w, y, w0.w * x));
         }
-        acc[m][4 * rg + 0] = t.x; acc[m][4 * rg + 1] = t.y; acc[m][4 * rg + 2] = t.z; acc[m][4 * rg + 3] = t.w;
         if constexpr (m == 0 && rg == 0) {           // first hook after the layer's first barrier: the aux slot has landed
             bias_q[0] = pb[0];
             if constexpr (ACT == ACT_FILM) { g_q[0] = pf[0]; bb_q[0] = pf[64]; }
@@ -367,14 +378,10 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     // The epilogue's LDS operands (bias, FiLM gamma|beta) are read ONE HOOK AHEAD into a two-deep register queue: a
     // ds_read consumed in the hook that issues it puts its whole round trip (~100 cycles > one MFMA's 64) on the
     // wave's in-order issue path, between two MFMAs.
+    // post(m, rg): one epilogue quarter = 4 registers, as two pairs on the packed fp32 ops (mi_math.h says why the
+    // instruction count is what matters).  LDS operands come from the one-quarter-ahead queue.
     const auto post = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value, idx = m * 4 + rg;
-        f32x4 g, bb, xo, co;
-        const f32x4 bias = bias_q[idx & 1];
-        if constexpr (ACT == ACT_FILM) {
-            g = g_q[idx & 1];
-            bb = bb_q[idx & 1];
-        }
         if constexpr (idx + 1 < MB * 4) {
             constexpr int m1 = (idx + 1) / 4, rg1 = (idx + 1) % 4;
             bias_q[(idx + 1) & 1] = pb[m1 * 8 + rg1];
@@ -383,32 +390,33 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
                 bb_q[(idx + 1) & 1] = pf[64 + m1 * 8 + rg1 * 2];
             }
         }
+        const f32x4 bias = bias_q[idx & 1];
+        f32x4 xo;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float v = __fadd_rn(acc[m][4 * rg + q], bias[q]);
-            float o;
-            if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
+        for (int q = 0; q < 4; q += 2) {
+            f32x2 v = f32x2{acc[m][4 * rg + q], acc[m][4 * rg + q + 1]} + f32x2{bias[q], bias[q + 1]};
+            f32x2 o;
+            if constexpr (ACT == ACT_RELU) o = f32x2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
             else if constexpr (ACT == ACT_LINEAR) o = v;
             else {
-                float u = v;
-                if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), bb[q]);
+                if constexpr (ACT == ACT_FILM) {
+                    const f32x4 g = g_q[idx & 1], bb = bb_q[idx & 1];
+                    v = film_affine(f32x2{g[q], g[q + 1]}, v, f32x2{bb[q], bb[q + 1]});
+                }
                 if constexpr (SAVE) {
-                    const SinCos sc = hw_sincos30(u);
+                    const SinSaved2 sc = hw_sin30_saved_x2(v);
                     o = sc.s;
-                    co[q] = 30.f * sc.c;
+                    xo[q] = sc.saved.x; xo[q + 1] = sc.saved.y;
                 } else {
-                    o = hw_sin30(u);
+                    o = hw_sin30_x2(v);
                 }
             }
-            X[m][4 * rg + q] = o;
-            xo[q] = o;
+            X[m][4 * rg + q] = o.x; X[m][4 * rg + q + 1] = o.y;
+            if constexpr (!kSinAct) { xo[q] = o.x; xo[q + 1] = o.y; }
         }
-        if constexpr (SAVE) {
-            if (sv.valid) {
-                const int64_t idx = m * 8 + rg * 2;    // float4 index inside the row (h folded into the row pointer)
-                if constexpr (!DEFER_X) reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[idx] = xo;
-                if constexpr (ACT == ACT_SIN30 || ACT == ACT_FILM) reinterpret_cast<f32x4*>(sv.c + sv.p * sv.ld + 4 * h)[idx] = co;
-            }
+        if constexpr (SAVE && (kSinAct || !DEFER_X)) {
+            // float4 index m*8 + rg*2 inside the row (h folded into the row pointer)
+            if (sv.valid) reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[m * 8 + rg * 2] = xo;
         }
     };
     if constexpr (SAVE && PREV_MB > 0) {
@@ -424,9 +432,9 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
                 if (pvalid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
         };
-        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
+        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
     } else {
-        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
+        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
     }
 }
 

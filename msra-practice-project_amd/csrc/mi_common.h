@@ -99,8 +99,12 @@ int64_t nerf_loss_workspace_floats(int64_t n);
 int launch_nerf_loss(int64_t n, const float* rgb_c, const float* acc_c, const float* rgb_f, const float* acc_f,
                      const float* target, int use_alpha, int use_fine, float* g_rgb_c, float* g_acc_c, float* g_rgb_f,
                      float* g_acc_f, float* workspace, float* out, hipStream_t stream);
-int launch_ray_bank(int width, int height, float focal, const float* poses, const float* rgba, int white_bkgd,
-                    int64_t images, float* out, hipStream_t stream);
+int launch_ray_bank(int width, int height, double focal, const float* poses, const float* rgba, int white_bkgd,
+                    int64_t images, float* out, int compute_f64, hipStream_t stream);
+int launch_adam_step(int n_fields, const int* kinds, const int* n_params, float* const* params, const float* const* grads,
+                     float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel, float step_size,
+                     float one_minus_beta1, float beta2, float one_minus_beta2, float eps, float bc2_sqrt,
+                     float* const* packed_fwd, float* const* packed_bwd, hipStream_t stream);
 int launch_sample_pdf(int64_t n, int nb, int ns, const float* bins, const float* weights, const float* u_lin, float* out,
                       hipStream_t stream);
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,

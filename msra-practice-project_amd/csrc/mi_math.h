@@ -63,10 +63,71 @@ __device__ __forceinline__ float hw_turns30(float u) {
 #pragma clang fp contract(off)
     return hw_turns(30.f * u);
 }
+#if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1     // diagnostic builds only (tools/diag_build.sh): no activation work at all
+__device__ __forceinline__ float hw_sin30(float u) { return u; }
+#elif defined(MI_DIAG_SIN) && MI_DIAG_SIN == 2   // ... the transcendental alone, no range reduction
+__device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(u); }
+#elif defined(MI_DIAG_SIN) && MI_DIAG_SIN == 3   // ... the reduction alone, no transcendental
+__device__ __forceinline__ float hw_sin30(float u) { return hw_turns30(u); }
+#else
 __device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(hw_turns30(u)); }
-__device__ __forceinline__ SinCos hw_sincos30(float u) {
-    const float f = hw_turns30(u);
-    return {__builtin_amdgcn_sinf(f), __builtin_amdgcn_cosf(f)};
+#endif
+
+// Two elements at a time on the packed fp32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, full rate on
+// gfx90a+): the wave runs ONE instruction stream per SIMD, and measured (tools/probes/mfma_valu_overlap.hip) every
+// VALU instruction issued between two MFMAs ADDS ~3 cycles to the 64 of the MFMA - there is no second wave on the
+// SIMD whose matrix work could cover it - so the activation's cost is its instruction count, and packing halves the
+// seven arithmetic instructions of the range reduction (v_rndne and v_sin have no packed form).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 hw_turns_x2(f32x2 t) {
+#pragma clang fp contract(off)
+    const f32x2 c_hi = {0.15915494309189535f, 0.15915494309189535f};
+    const float cl = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    const f32x2 c_lo = {cl, cl};
+    const f32x2 hi = t * c_hi;
+    const f32x2 lo = __builtin_elementwise_fma(t, c_lo, __builtin_elementwise_fma(t, c_hi, -hi));
+    const f32x2 k = {rintf(hi.x), rintf(hi.y)};
+    return (hi - k) + lo;
+}
+__device__ __forceinline__ f32x2 hw_turns30_x2(f32x2 u) {
+#pragma clang fp contract(off)
+    const f32x2 w0 = {30.f, 30.f};
+    return hw_turns_x2(u * w0);
+}
+__device__ __forceinline__ f32x2 hw_sin30_x2(f32x2 u) {
+    const f32x2 r = hw_turns30_x2(u);
+    return f32x2{__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y)};
+}
+
+// Training: what the backward needs of a sin layer is its output X = sin(30 u) (the next layer's dW operand) and the
+// derivative factor C = 30 cos(30 u).  Only X is kept, with the SIGN of the cosine in its lowest mantissa bit
+// (the reduced angle r is at hand: cos < 0 iff |r| > 1/4 turn), and the backward rebuilds
+// C = +-30 sqrt(1 - X^2).  Halves the saved bytes per point (18.5 -> 9.3 KB for the FiLM field) and saves the v_cos.
+// Cost in accuracy: X' differs from X by <= 1 ulp (6e-8 relative, below the dW GEMM's own rounding), and the rebuilt
+// |cos| carries X's 2e-7 error amplified by |X|/|cos|: more than 2e-4 absolute only where |cos| < 1e-3, i.e. for
+// 0.06 % of the units - 2e-5 of the factor's RMS, against the 5e-4 relative gate on every gradient tensor.
+struct SinSaved { float s, saved; };
+__device__ __forceinline__ SinSaved hw_sin30_saved(float u) {
+    const float r = hw_turns30(u);
+    const float sn = __builtin_amdgcn_sinf(r);
+    const unsigned neg = fabsf(r) > 0.25f ? 1u : 0u;
+    return {sn, __uint_as_float((__float_as_uint(sn) & ~1u) | neg)};
+}
+__device__ __forceinline__ float dsin30_from_saved(float xs) {
+    // 900 (1 - X^2); |X| <= 1 makes it non-negative, and the |.| (a free source modifier of v_sqrt) keeps a
+    // transcendental-unit result one ulp above 1 from turning into a NaN
+    const float y = fmaf(xs * -900.f, xs, 900.f);
+    return __uint_as_float(__float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y))) ^ (__float_as_uint(xs) << 31));
+}
+struct SinSaved2 { f32x2 s, saved; };
+__device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {
+    const f32x2 r = hw_turns30_x2(u);
+    const f32x2 sn = {__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y)};
+    SinSaved2 o;
+    o.s = sn;
+    o.saved.x = __uint_as_float((__float_as_uint(sn.x) & ~1u) | (fabsf(r.x) > 0.25f ? 1u : 0u));
+    o.saved.y = __uint_as_float((__float_as_uint(sn.y) & ~1u) | (fabsf(r.y) > 0.25f ? 1u : 0u));
+    return o;
 }
 
 }  // namespace mi

@@ -43,7 +43,10 @@ SIGNATURES = {
     "mi_grid_points": (_int, [_int, _vp, _f32, _i64, _i64, _vp, _vp]),
     "mi_nerf_loss_workspace_floats": (_i64, [_i64]),
     "mi_nerf_loss": (_int, [_i64, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mi_ray_bank": (_int, [_int, _int, _f32, _vp, _vp, _int, _i64, _vp, _vp]),
+    "mi_ray_bank": (_int, [_int, _int, _f64, _vp, _vp, _int, _i64, _vp, _int, _vp]),
+    "mi_adam_step": (_int, [_int, ctypes.POINTER(_int), ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                            ctypes.POINTER(_vp), ctypes.POINTER(_i64), _f32, _f32, _f32, _f32, _f32, _f32,
+                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "mi_render_workspace_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
                               _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

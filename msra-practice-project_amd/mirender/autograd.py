@@ -18,7 +18,9 @@ from . import _lib, fields, ops
 
 CHUNK_BYTES = 48 << 30         # saved activations + per-layer gradients per ray range (288 GB of HBM)
 SAVE_COARSE_BYTES = 48 << 30   # layer inputs the forward may keep for the coarse pass (no recompute in backward) ...
-SAVE_FINE_BYTES = 160 << 30    # ... and for the fine pass; both also limited to half of the free memory
+SAVE_FINE_BYTES = 208 << 30    # ... and for the fine pass; both also limited to the free memory minus RESERVE_BYTES
+RESERVE_BYTES = CHUNK_BYTES + (16 << 30)   # what backward needs besides the kept inputs: one range's recomputed inputs
+#                                            + gradients (CHUNK_BYTES by construction), reduction scratch, raw / depths
 
 
 def _max_points_per_chunk(pf) -> int:
@@ -74,9 +76,11 @@ def _film_of_range(f_all, rpg, r0, r1):
 
 
 def _save_budget(dev, cap: int) -> int:
-    """Bytes of layer inputs the forward may keep: `cap`, but never more than half of what is free right now."""
+    """Bytes of layer inputs the forward may keep: `cap`, but never more than what is free right now (the driver's
+    figure plus what torch's caching allocator holds unused) minus RESERVE_BYTES."""
     free, _total = torch.cuda.mem_get_info(dev)
-    return max(0, min(cap, free // 2))
+    cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return max(0, min(cap, free + cached - RESERVE_BYTES))
 
 
 def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothing: bool = False):

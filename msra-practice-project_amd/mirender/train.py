@@ -4,24 +4,31 @@
   nerf_loss    loss + psnr of one batch, one kernel        train_nerf.py:158-167
   decayed_lr   the learning-rate schedule                  train_nerf.py:170-175
 
-The optimiser stays torch.optim.Adam (train_nerf.py:96); pass fused=True to update all tensors in one launch.
+  FusedAdam    torch.optim.Adam's step + the repack of both   train_nerf.py:98, 168
+               MFMA weight streams, one launch
 """
 from __future__ import annotations
+
+import ctypes
+import math
 
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, fields
 
 
 class RayBank:
     """rays_rgba [N*H*W, 10] = (rays_o, rays_d, r, g, b, a) for every pixel of every training image, built and
     shuffled on the device.  images [N,H,W,4] (RGBA in [0,1]), poses [N,>=3,4] camera-to-world, focal a float.
 
-    Unlike the reference the per-epoch reshuffle takes effect (train_nerf.py:144 assigns the permuted table to
-    a misspelt name, so every epoch replays the first one)."""
+    By default the per-epoch reshuffle takes effect; the reference's does not (train_nerf.py:144 assigns the permuted
+    table to a misspelt name, so every epoch replays the first shuffle): `reshuffle=False` reproduces that for
+    trajectory comparisons.  `focal` may be a Python float or - as nerf/data_loader.py:151 returns it - an np.float64
+    scalar, in which case NumPy >= 2 evaluates get_rays in fp64 (train_nerf.py:78) and the table follows suit."""
 
-    def __init__(self, images, poses, focal: float, device="cuda", white_bkgd: bool = True, generator=None):
+    def __init__(self, images, poses, focal: float, device="cuda", white_bkgd: bool = True, generator=None,
+                 reshuffle: bool = True):
         lib = _lib.load()
         dev = torch.device(device)
         images = torch.as_tensor(np.asarray(images) if not isinstance(images, torch.Tensor) else images)
@@ -31,11 +38,12 @@ class RayBank:
             raise _lib.MiRenderError("RayBank expects RGBA images [N,H,W,4]")
         poses = torch.as_tensor(np.asarray(poses) if not isinstance(poses, torch.Tensor) else poses)
         poses = poses.to(dtype=torch.float32)[:, :3, :4].contiguous().reshape(n, 12).to(dev)
-        self.width, self.height, self.generator = w, h, generator
+        self.width, self.height, self.generator, self.reshuffle = w, h, generator, reshuffle
         self.table = torch.empty((n * h * w, 10), dtype=torch.float32, device=dev)
+        f64 = isinstance(focal, np.floating) and np.dtype(type(focal)) == np.float64      # as ops.gen_rays
         with torch.cuda.device(dev):
             _lib.check(lib.mi_ray_bank(w, h, float(focal), _lib.ptr(poses), _lib.ptr(images), int(white_bkgd), n,
-                                       _lib.ptr(self.table), _lib.stream_ptr(dev)), "mi_ray_bank")
+                                       _lib.ptr(self.table), int(f64), _lib.stream_ptr(dev)), "mi_ray_bank")
         self.batch_idx = 0
 
     def __len__(self):
@@ -54,7 +62,9 @@ class RayBank:
         b = self.table[self.batch_idx * batch_size:(self.batch_idx + 1) * batch_size]
         self.batch_idx += 1
         if self.batch_idx == n_batches:
-            self.shuffle()
+            if self.reshuffle:
+                self.shuffle()
+            self.batch_idx = 0
         return b[:, :6].reshape(-1, 2, 3), b[:, 6:9], b[:, 9]
 
 
@@ -97,3 +107,109 @@ def nerf_loss(outputs, batch_rgb, batch_alpha, use_alpha: bool = False, use_fine
 def decayed_lr(learning_rate: float, learning_rate_decay: float, global_step: int, decay_rate: float = 0.1) -> float:
     """train_nerf.py:170-173: lr * 0.1 ** (step / (learning_rate_decay * 1000))."""
     return learning_rate * (decay_rate ** (global_step / (learning_rate_decay * 1000)))
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr, betas) of nerf/train_nerf.py:98 for the parameters of one or two fused field
+    modules, with the same interface the script uses - `zero_grad()`, `step()`, `param_groups[i]['lr'] = ...`
+    (train_nerf.py:174-175), `state_dict()` / `load_state_dict()` in torch.optim.Adam's own format, so the
+    'optimizer' entry of a checkpoint moves freely between the two (train_nerf.py:110,187).
+
+    One C-ABI call per step (mi_adam_step): every tensor's Adam update AND the refresh of both packed MFMA weight
+    streams of each model in a single launch; a torch optimiser step is followed by two pack launches per model at
+    the next forward / backward.  Arithmetic follows torch's multi-tensor Adam op by op (parity 1e-7 over 10 steps:
+    tests/test_gpu_trainloop.py)."""
+
+    def __init__(self, models, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        models = [models] if isinstance(models, torch.nn.Module) else list(models)
+        if not 1 <= len(models) <= 2:
+            raise _lib.MiRenderError("FusedAdam takes one or two field modules (coarse, fine)")
+        self.fields = []
+        for m in models:
+            pf = fields.as_packed_field(m)
+            if pf is None:
+                raise _lib.MiRenderError("FusedAdam needs modules with a known field layout (fields.detect_kind)")
+            if pf not in self.fields:                      # coarse_model is fine_model (use_fine_model off): one field
+                self.fields.append(pf)
+        self.params = [p for pf in self.fields for p in pf.params]
+        self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False,
+                                  maximize=False, foreach=None, capturable=False, differentiable=False, fused=None)]
+        self.state = {}
+        self._step = 0
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            if p.grad is not None:
+                if set_to_none:
+                    p.grad = None
+                else:
+                    p.grad.zero_()
+
+    def _ensure_state(self):
+        for p in self.params:
+            if p not in self.state:
+                self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=torch.zeros_like(p),
+                                     exp_avg_sq=torch.zeros_like(p))
+
+    @torch.no_grad()
+    def step(self):
+        lib = _lib.load()
+        g = self.param_groups[0]
+        lr, (beta1, beta2), eps = float(g["lr"]), g["betas"], float(g["eps"])
+        if any(p.grad is None for p in self.params):
+            raise _lib.MiRenderError("FusedAdam.step: every parameter needs a gradient (run backward first)")
+        self._ensure_state()
+        self._step += 1
+        t = self._step
+        bc1 = 1 - beta1 ** t
+        bc2_sqrt = math.sqrt(1 - beta2 ** t)
+        n = len(self.params)
+        dev = self.fields[0].device
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in self.params]
+        for p, gr in zip(self.params, grads):
+            if not p.is_contiguous() or gr.dtype != torch.float32 or gr.device != p.device:
+                raise _lib.MiRenderError("FusedAdam: parameters and gradients must be contiguous fp32 on one device")
+        arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])  # noqa: E731
+        kinds = (ctypes.c_int * len(self.fields))(*[pf.kind for pf in self.fields])
+        numel = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
+        # the streams must hold the current parameters before their changed entries are scattered into them
+        fwd = [pf.refresh() for pf in self.fields]
+        bwd = [pf.refresh_bwd() if pf.packed_bwd is not None else None for pf in self.fields]
+        pfwd = (ctypes.c_void_p * len(fwd))(*[x.data_ptr() for x in fwd])
+        pbwd = (ctypes.c_void_p * len(bwd))(*[None if x is None else x.data_ptr() for x in bwd])
+        with torch.cuda.device(dev):
+            _lib.check(lib.mi_adam_step(len(self.fields), kinds, arr(self.params), arr(grads),
+                                        arr([self.state[p]["exp_avg"] for p in self.params]),
+                                        arr([self.state[p]["exp_avg_sq"] for p in self.params]), numel,
+                                        -lr / bc1, 1 - beta1, beta2, 1 - beta2, eps, bc2_sqrt, pfwd, pbwd,
+                                        _lib.stream_ptr(dev)), "mi_adam_step")
+        for p in self.params:
+            self.state[p]["step"] += 1
+        # the kernel wrote parameters and streams together; the version counters did not move, so the lazily
+        # refreshed streams stay valid.  (A stream that did not exist yet is built from the parameters on first use.)
+
+    # -- torch.optim.Adam's state-dict format ------------------------------------------------------------------
+    def state_dict(self):
+        self._ensure_state() if self._step else None
+        state = {i: {k: v.clone() for k, v in self.state[p].items()} for i, p in enumerate(self.params) if p in self.state}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.params)))
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        group = dict(sd["param_groups"][0])
+        if len(group["params"]) != len(self.params):
+            raise ValueError("loaded state dict has a different number of parameters")
+        for k in ("lr", "betas", "eps"):
+            self.param_groups[0][k] = tuple(group[k]) if k == "betas" else group[k]
+        self.state = {}
+        steps = set()
+        for i, st in sd["state"].items():
+            p = self.params[int(i)]
+            self.state[p] = dict(step=torch.as_tensor(st["step"], dtype=torch.float32).clone().cpu(),
+                                 exp_avg=st["exp_avg"].to(device=p.device, dtype=torch.float32).clone().contiguous(),
+                                 exp_avg_sq=st["exp_avg_sq"].to(device=p.device, dtype=torch.float32).clone().contiguous())
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdam keeps one step count for all parameters")
+        self._step = steps.pop() if steps else 0

@@ -110,3 +110,124 @@ def test_one_training_step_matches_torch_loss(mi):
     for a, b in zip(grads[0][2], grads[1][2]):
         assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
     assert mi.train.decayed_lr(5e-4, 500, 250000) == 5e-4 * 0.1 ** 0.5
+
+
+@pytest.mark.parametrize("kinds", [("nerf", "nerf"), ("tiny_nerf",), ("siren_nerf", "nerf"), ("film_siren_nerf",),
+                                   ("film_siren_nerf_nodir", "tiny_nerf")])
+def test_fused_adam_matches_torch_adam_and_keeps_the_streams_current(mi, kinds):
+    """FusedAdam (mi_adam_step: Adam on every tensor + scatter of the new values into both packed MFMA streams, one
+    launch) against torch.optim.Adam(lr, betas=(0.9, 0.999)) of nerf/train_nerf.py:98 on identical gradients for 10
+    steps with the script's learning-rate decay (train_nerf.py:170-175): parameters and both Adam moments within 1e-7;
+    after every step the streams the kernel patched in place equal a fresh pack of the updated parameters bit for
+    bit (forward order and, where it exists, the transposed order of the backward chain)."""
+    torch.manual_seed(0)
+    mods_a = [mi.fields.field_from_state_dict(synth.state_dict(k, seed=80 + i, sharp="medium", bias_jitter=0.05), dev())
+              for i, k in enumerate(kinds)]
+    mods_b = [mi.fields.field_from_state_dict(synth.state_dict(k, seed=80 + i, sharp="medium", bias_jitter=0.05), dev())
+              for i, k in enumerate(kinds)]
+    pfs = [mi.fields.as_packed_field(m) for m in mods_a]
+    pfs[0].refresh_bwd()                                   # field 0 has a transposed stream, field 1 (if any) not yet
+    for pf in pfs:
+        pf.refresh()
+    fused = mi.train.FusedAdam(mods_a, lr=5e-4, betas=(0.9, 0.999))
+    params_b = [p for m in mods_b for p in m.parameters()]
+    ref = torch.optim.Adam(params_b, lr=5e-4, betas=(0.9, 0.999))
+    assert [tuple(p.shape) for p in fused.params] == [tuple(p.shape) for p in params_b]
+    gen = torch.Generator(device=dev()).manual_seed(1)
+    for step in range(10):
+        for pa, pb in zip(fused.params, params_b):
+            g = torch.randn(pa.shape, device=dev(), generator=gen) * (10.0 ** float(torch.randint(-4, 1, (1,)).item()))
+            pa.grad, pb.grad = g.clone(), g.clone()
+        fused.step()
+        ref.step()
+        lr = mi.train.decayed_lr(5e-4, 0.5, step + 1)     # fast decay so the schedule matters within 10 steps
+        for group in list(fused.param_groups) + list(ref.param_groups):
+            group["lr"] = lr
+        for pa, pb in zip(fused.params, params_b):
+            assert float((pa - pb).abs().max()) <= 1e-7
+        for pf in pfs:                                      # streams patched in place == repacked from scratch
+            fresh = mi.fields.PackedField(pf.kind, pf.params)
+            assert torch.equal(pf.packed, fresh.refresh())
+            if pf.packed_bwd is not None:
+                assert torch.equal(pf.packed_bwd, fresh.refresh_bwd())
+    for pa, pb in zip(fused.params, params_b):
+        sa, sb = fused.state[pa], ref.state[pb]
+        assert float(sa["step"]) == float(sb["step"]) == 10.0
+        assert float((sa["exp_avg"] - sb["exp_avg"]).abs().max()) <= 1e-7 * max(1.0, float(sb["exp_avg"].abs().max()))
+        assert float((sa["exp_avg_sq"] - sb["exp_avg_sq"]).abs().max()) <= 1e-7 * max(1.0, float(sb["exp_avg_sq"].abs().max()))
+    # the renderer sees the updated weights without any repack (version counters did not move)
+    x = torch.rand(300, 6, device=dev()) * 2 - 1
+    film = synth.film_params(1, seed=2).to(dev())
+    for ma, mb, k in zip(mods_a, mods_b, kinds):
+        f = film if k.startswith("film") else None
+        a = mi.fields.eval_points(mi.fields.as_packed_field(ma), x, f)
+        b = mi.fields.eval_points(mi.fields.as_packed_field(mb), x, f)
+        assert float((a - b).abs().max()) <= 1e-4
+    # state dicts are interchangeable with torch.optim.Adam's in both directions (checkpoint 'optimizer' entry)
+    sd = fused.state_dict()
+    ref2 = torch.optim.Adam([p for m in mods_a for p in m.parameters()], lr=1.0)
+    ref2.load_state_dict(sd)
+    assert ref2.param_groups[0]["lr"] == fused.param_groups[0]["lr"] and float(ref2.state[fused.params[0]]["step"]) == 10.0
+    fused2 = mi.train.FusedAdam(mods_b, lr=1.0)
+    fused2.load_state_dict(ref.state_dict())
+    for pa, pb in zip(fused.params, fused2.params):
+        g = torch.randn(pa.shape, device=dev(), generator=gen) * 1e-2
+        pa.grad, pb.grad = g.clone(), g.clone()
+    fused.step()
+    fused2.step()
+    for pa, pb in zip(fused.params, fused2.params):
+        assert float((pa - pb).abs().max()) <= 2e-7
+
+
+def test_fused_adam_in_the_training_step(mi):
+    """The loop of nerf/train_nerf.py:124-176 with FusedAdam in place of torch.optim.Adam: same losses (1e-5 relative
+    after 6 steps); coarse_model is fine_model (use_fine_model off) is one field, updated once."""
+    W, H = 12, 9
+    poses = np.stack([synth.pose_degrees(4.0, th, -30.0) for th in (20.0, -60.0)]).astype(np.float32)
+    imgs = np.random.Generator(np.random.PCG64(5)).random((2, H, W, 4), dtype=np.float32)
+    losses = {}
+    for which in ("fused", "torch"):
+        bank = mi.train.RayBank(imgs, poses, 1.3875 * W, dev(), generator=torch.Generator(device=dev()).manual_seed(1))
+        bank.shuffle()
+        cm = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=60, sharp="medium", bias_jitter=0.05), dev())
+        fm = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=61, sharp="medium", bias_jitter=0.05), dev())
+        params = list(cm.parameters()) + list(fm.parameters())
+        opt = mi.train.FusedAdam([cm, fm], lr=5e-4) if which == "fused" else torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+        out = []
+        for step in range(6):
+            rays, rgb, alpha = bank.batch(54)                 # 216 rays: four full batches per epoch
+            outs = mi.render_core.render_rays(rays, 2.0, 6.0, cm, fm, 8, 8, t_rand=synth.t_rand(54, 8, seed=step).to(dev()))
+            loss, _ = mi.train.nerf_loss(outs, rgb, alpha, use_alpha=True, use_fine_model=True)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        losses[which] = out
+    for a, b in zip(losses["fused"], losses["torch"]):
+        assert abs(a - b) <= 1e-5 * abs(b), (losses,)
+    assert losses["fused"][-1] < losses["fused"][0]
+    m = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=62), dev())
+    assert len(mi.train.FusedAdam([m, m]).fields) == 1
+
+
+def test_ray_bank_float64_focal_and_reference_reshuffle_quirk(mi):
+    """focal as nerf/data_loader.py:151 returns it (an np.float64 scalar): NumPy >= 2 then evaluates get_rays in fp64
+    (train_nerf.py:78) before train_nerf.py:84 rounds to fp32 - the table must follow.  reshuffle=False reproduces the
+    reference's dead epoch shuffle (train_nerf.py:144 assigns to a misspelt name): every epoch replays the first."""
+    W, H, n = 9, 7, 2
+    focal64 = np.float64(0.5 * W / np.tan(0.5 * 0.6911112))          # data_loader.py:151
+    poses = np.stack([synth.pose_degrees(4.0, th, -30.0) for th in (37.0, -120.0)]).astype(np.float32)
+    imgs = np.random.Generator(np.random.PCG64(3)).random((n, H, W, 4), dtype=np.float32)
+    bank = mi.train.RayBank(imgs, poses, focal64, dev())
+    exp = T.rays_rgba(imgs, poses, W, H, focal64)
+    assert np.array_equal(bank.table.cpu().numpy(), exp)
+    bank32 = mi.train.RayBank(imgs, poses, float(focal64), dev())
+    assert np.array_equal(bank32.table.cpu().numpy(), T.rays_rgba(imgs, poses, W, H, float(focal64)))
+    assert not np.array_equal(bank.table.cpu().numpy(), bank32.table.cpu().numpy())      # the promotion matters
+    quirk = mi.train.RayBank(imgs, poses, float(focal64), dev(), reshuffle=False,
+                             generator=torch.Generator(device=dev()).manual_seed(2))
+    quirk.shuffle()
+    first = [quirk.batch(50)[0].clone() for _ in range(3)]          # 126 rays: 3 batches per epoch
+    again = [quirk.batch(50)[0].clone() for _ in range(3)]
+    for a, b in zip(first, again):
+        assert torch.equal(a, b)

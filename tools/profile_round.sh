@@ -8,12 +8,23 @@ mkdir -p gpurun_out && export TMPDIR=/tmp
 timeout -k 10 400 python3 bench.py --steps 5 --warmup 1 2>&1 | tail -1 > gpurun_out/bench.log || exit 1
 cut -c1-600 gpurun_out/bench.log
 rm -rf gpurun_out/prof_stats
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-frame64 > gpurun_out/prof_stats.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-frame64 --no-train > gpurun_out/prof_stats.log 2>&1 || exit 1
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" \
          "GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS"; do
     d=$(echo $c | tr " " "_" | cut -c1-40)
     rm -rf gpurun_out/pmc_$d
-    timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-frame64 > gpurun_out/pmc_$d.log 2>&1 || exit 1
+    timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-frame64 --no-train > gpurun_out/pmc_$d.log 2>&1 || exit 1
     echo "pmc $d ok"
+done
+# training workloads: kernel stats + HBM / MFMA-busy counters of one step each (C4 = pi_GAN generator step, nerf 1024-ray step)
+for wl in c4 nerf_train; do
+    rm -rf gpurun_out/prof_stats_$wl
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_$wl -- python3 bench.py --workload $wl --steps 3 --warmup 1 > gpurun_out/prof_stats_$wl.log 2>&1 || exit 1
+    for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        d=${wl}_$(echo $c | tr " " "_" | cut -c1-30)
+        rm -rf gpurun_out/pmct_$d
+        timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmct_$d -- python3 bench.py --workload $wl --steps 1 --warmup 1 > gpurun_out/pmct_$d.log 2>&1 || exit 1
+        echo "pmc $d ok"
+    done
 done

@@ -69,3 +69,51 @@ json.dump({
     "launch_points": [l["points"] for l in launches], "launch_ms": [l["ms"] for l in launches],
     "counters": counters, "derived_fine_launch": derived}, open(os.path.join(out_dir, f"{tag}_pmc_nerf_fwd.json"), "w"), indent=1)
 print(json.dumps(derived, indent=1))
+
+
+# ---- training workloads: per-kernel HBM traffic and MFMA-busy fraction over the traced run (profile_round.sh) ----
+def train_summary(wl):
+    per_kernel = {}
+    for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmct_{wl}_*"))):
+        if not os.path.isdir(d):
+            continue
+        f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not name.startswith("mi::"):
+                continue
+            k = per_kernel.setdefault(name, {"launches": 0, "ms": 0.0})
+            if r["Counter_Name"] == "FETCH_SIZE":                 # one row per dispatch in that pass: count and time it
+                k["launches"] += 1
+                k["ms"] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+            k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    out = {}
+    for name, k in per_kernel.items():
+        if not k.get("ms"):
+            continue
+        hbm = (2 * k.get("FETCH_SIZE", 0.0) + k.get("WRITE_SIZE", 0.0)) * 1024
+        row = {"launches": k["launches"], "ms": k["ms"], "hbm_bytes_2xFETCH_plus_WRITE": hbm,
+               "hbm_GBps": hbm / (k["ms"] * 1e-3) / 1e9}
+        if k.get("GRBM_GUI_ACTIVE"):
+            row["mfma_busy_frac"] = k.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (k["GRBM_GUI_ACTIVE"] * 128)
+        out[name] = row
+    stats = newest(f"prof_stats_{wl}/**/*kernel_stats.csv")
+    if stats:
+        shutil.copy(stats, os.path.join(out_dir, f"{tag}_bench_{wl}_kernel_stats.csv"))
+    log = os.path.join(ROOT, "gpurun_out", f"prof_stats_{wl}.log")
+    if os.path.exists(log):
+        line = [l for l in open(log) if l.startswith("{")]
+        if line:
+            open(os.path.join(out_dir, f"{tag}_bench_{wl}.log"), "w").write(line[-1])
+    if out:
+        json.dump({"command": f"rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --workload {wl} --steps 1 --warmup 1 "
+                              "(one pass per counter group; sums over the warm-up and the timed step)",
+                   "note": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH doubled for gfx950 (MI355X_MICROARCH.md)", "kernels": out},
+                  open(os.path.join(out_dir, f"{tag}_pmc_{wl}.json"), "w"), indent=1)
+        top = sorted(out.items(), key=lambda kv: -kv[1]["ms"])[:6]
+        for name, row in top:
+            print(f"{wl:10s} {name[:60]:60s} {row['ms']:9.2f} ms {row['hbm_GBps']:8.1f} GB/s  busy {row.get('mfma_busy_frac', float('nan')):.3f}")
+
+
+for wl in ("c4", "nerf_train"):
+    train_summary(wl)
