@@ -5,10 +5,11 @@
 // build: hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_valu_overlap.hip -o gpurun_tools/mfma_valu_overlap
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int N, int DEP, int KIND>
-__global__ __launch_bounds__(256, 1) void k(float* out, int iters, float seed) {
+__global__ __launch_bounds__(256, 2) void k(float* out, int iters, float seed) {
     f32x16 acc[8];
     for (int m = 0; m < 8; ++m) for (int r = 0; r < 16; ++r) acc[m][r] = seed * (m + r);
     float a = seed + threadIdx.x, b = seed * 2.f;
@@ -44,9 +45,10 @@ __global__ __launch_bounds__(256, 1) void k(float* out, int iters, float seed) {
     if (threadIdx.x == 0 && blockIdx.x == 0) out[256 * gridDim.x] = (float)(t1 - t0) / (iters * 64.f);
 }
 
+static int g_blocks = 256;       // 256: one wave per SIMD; 512: two (the kernel needs few registers, so two workgroups fit a CU)
 template <int N, int DEP, int KIND>
 void run(float* d, const char* tag) {
-    const int blocks = 256, iters = 200;
+    const int blocks = g_blocks, iters = 200;
     hipLaunchKernelGGL((k<N, DEP, KIND>), dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
     (void)hipDeviceSynchronize();
     hipEvent_t e0, e1;
@@ -58,12 +60,14 @@ void run(float* d, const char* tag) {
     float ms = 0, cyc = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipMemcpy(&cyc, d + 256 * blocks, 4, hipMemcpyDeviceToHost);
-    printf("%-28s N=%2d  %.1f ns per MFMA  (clock64 ticks per MFMA %.1f)\n", tag, N, ms * 1e6 / (iters * 64.0), cyc);
+    printf("%-28s N=%2d  waves/SIMD %d  %.1f ns per MFMA of one wave, %.1f ns per MFMA per SIMD (clock64 ticks per MFMA of one wave %.1f)\n",
+           tag, N, blocks / 256, ms * 1e6 / (iters * 64.0), ms * 1e6 / (iters * 64.0) / (blocks / 256), cyc);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_blocks = atoi(argv[1]);
     float* d;
-    (void)hipMalloc(&d, (256 * 256 + 16) * 4);
+    (void)hipMalloc(&d, (1024 * 256 + 16) * 4);
 #define ROW(DEP, KIND, TAG) run<0, DEP, KIND>(d, TAG); run<2, DEP, KIND>(d, TAG); run<4, DEP, KIND>(d, TAG); run<6, DEP, KIND>(d, TAG); \
     run<8, DEP, KIND>(d, TAG); run<10, DEP, KIND>(d, TAG); run<12, DEP, KIND>(d, TAG); run<14, DEP, KIND>(d, TAG); run<16, DEP, KIND>(d, TAG); run<20, DEP, KIND>(d, TAG);
     ROW(0, 0, "8 independent v_fma chains")
