@@ -215,6 +215,15 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     achieved = flops * steps / elapsed / 1e12
+    # HBM bytes per step: not measurable from inside the process; from the committed rocprofv3 PMC passes of this same
+    # workload (profiles/r02_pmc_<workload>.json: WRITE_SIZE + 2 x FETCH_SIZE summed over every kernel of the two traced
+    # steps, tools/summarise_pmc.py).  null if absent.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{workload}.json")))
+        traffic = sum(k["hbm_bytes_2xFETCH_plus_WRITE"] for k in pmc["kernels"].values()) / 2
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "metric": "rays/sec (training step)", "value": world * rays_per_step * steps / elapsed, "unit": "rays/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
@@ -223,7 +232,8 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
                    "parallelism": f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU"},
         "roofline": {"bound": "mfma", "kernel": "whole training step (forward, backward chain, dW GEMMs)",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "traffic_unit": f"HBM bytes per step (PMC, profiles/r02_pmc_{workload}.json)",
                      "note": "algorithmic FLOPs = 2 x MACs x (1 per no-grad pass + 3 per trained pass), SURVEY.md 8d"},
     }
 
@@ -302,10 +312,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # Rehearsal switch for boxes with fewer GPUs than ranks (the build sessions have one): MI_BENCH_REHEARSAL=1 puts every
+    # rank on device 0 and moves the collectives over gloo (RCCL refuses two ranks per device).  Never set by the driver;
+    # the line says so in config.parallelism when it is.
+    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     if args.workload != "c3":
         line = train_workload(args, world, rank, dev)
         if rank == 0:
@@ -433,7 +452,8 @@ def main():
                                    "NeRF 8x256 (BASELINE config C3), random-init weights (sigma head x50), "
                                    "in-kernel Philox jitter, rays generated on device",
                        "rays_per_step": W * H, "mlp_evals_per_ray": NC + NC + NF,
-                       "parallelism": f"ray-shard x{world} + RCCL all-gather" if world > 1 else "single GPU"},
+                       "parallelism": (f"ray-shard x{world} + RCCL all-gather" if world > 1 else "single GPU")
+                       + (" [REHEARSAL: all ranks on one device, gloo]" if rehearsal else "")},
             "roofline": roofline,
         }
         if f64_s is not None:

@@ -171,12 +171,16 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             for (int q = 0; q < 4; ++q) sv[j - 8][q] = dsin30_from_saved(sv[j - 8][q]);
         }
         if constexpr (kb < 4 && slot < 16) {
+#ifdef MI_DIAG_NOROWS      // diagnostic builds only (tools/diag_build.sh): no row traffic at all, to price its interference
+            if constexpr ((slot & 1) == 0) { if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = f32x4{1.f, 1.f, 1.f, 1.f}; }
+#else
             if constexpr ((slot & 1) == 0) {
                 if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
             } else if constexpr (j < PREV_MB * 4) {
                 constexpr int m = j / 4, rg = j % 4;
                 if (valid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
+#endif
         }
     };
     const auto post = [&](auto mc, auto pc) {
@@ -192,7 +196,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             if constexpr (EPI == EPI_FILM) X[m][4 * rg + q] = o[q] * g[q];
             else X[m][4 * rg + q] = o[q];
         }
-        if constexpr (!DEFER) { if (valid) drow[m * 8 + rg * 2] = o; }
+        if constexpr (!DEFER) { if (valid) drow[m * 8 + rg * 2] = o; }   // (kept in MI_DIAG_NOROWS: keeps the chain live)
     };
     mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
                                                               NoHook{}, bsel, acc, pre, post, mid);

@@ -3,7 +3,10 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "msra-practice-project_amd")]
 import torch
-from mirender import fields, render_core, train
+from mirender import _lib, fields, render_core, train
+if os.environ.get("MI_DIAG_LIB"):       # a diagnostic build of the library (tools/diag_build.sh), this tool only
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["MI_DIAG_LIB"])
+    print("using", _lib.LIB_PATH, flush=True)
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 cm, fm = fields.NeRF().to(dev), fields.NeRF().to(dev)
