@@ -171,8 +171,16 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             for (int q = 0; q < 4; ++q) sv[j - 8][q] = dsin30_from_saved(sv[j - 8][q]);
         }
         if constexpr (kb < 4 && slot < 16) {
-#ifdef MI_DIAG_NOROWS      // diagnostic builds only (tools/diag_build.sh): no row traffic at all, to price its interference
-            if constexpr ((slot & 1) == 0) { if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = f32x4{1.f, 1.f, 1.f, 1.f}; }
+#ifdef MI_DIAG_NOROWS      // diagnostic builds only (tools/diag_build.sh): 1 = no row loads, 2 = no deferred row stores, 3 = neither
+            if constexpr ((slot & 1) == 0) {
+                if constexpr (EPI != EPI_LINEAR && j < MB * 4) {
+                    if constexpr (MI_DIAG_NOROWS & 1) sv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+                    else sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
+                }
+            } else if constexpr (j < PREV_MB * 4 && !(MI_DIAG_NOROWS & 2)) {
+                constexpr int m = j / 4, rg = j % 4;
+                if (valid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+            }
 #else
             if constexpr ((slot & 1) == 0) {
                 if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
@@ -1193,6 +1201,15 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
         else if (kind == 4) hipLaunchKernelGGL(nerf_bwd_kernel<true>, dim3(blocks), dim3(256), lds, stream, a);
         else hipLaunchKernelGGL(siren_bwd_kernel, dim3(blocks), dim3(256), lds, stream, a);
         if ((rc = check_launch("backward chain"))) return rc;
+        // dry run first (no launches): the scratch this very pass needs must fit what mi_field_bwd_partial_floats told the
+        // caller to allocate - a planning / execution mismatch would otherwise be an out-of-bounds write by the GEMMs
+        BwdBatcher plan{P, nullptr, 0, stream};
+        (void)batched_backward(kind, plan, acts, grads, gp);
+        if (plan.used > bwd_partial_floats(P)) {
+            set_error("backward scratch plan (%lld floats) exceeds mi_field_bwd_partial_floats (%lld)", (long long)plan.used,
+                      (long long)bwd_partial_floats(P));
+            return -1;
+        }
         BwdBatcher bb{P, partial, 0, stream};
         if ((rc = batched_backward(kind, bb, acts, grads, gp))) return rc;
     } else if (kind == 2 || kind == 3) {
@@ -1251,9 +1268,14 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
 }
 
 static int64_t batched_partial_floats(int kind, int64_t P) {
-    static float* const none[24] = {};
+    // Plan only (partial == nullptr: nothing is launched, nothing dereferenced).  The gradient pointers must be NON-null
+    // here: a job's record is TM*TK floats plus TM bias sums when it has a bias destination, and a plan made with null
+    // destinations comes out 256 floats per record short of what the real pass writes.
+    static float sink;
+    float* gp[24];
+    for (float*& g : gp) g = &sink;
     BwdBatcher bb{P, nullptr, 0, nullptr};
-    (void)batched_backward(kind, bb, nullptr, nullptr, none);
+    (void)batched_backward(kind, bb, nullptr, nullptr, gp);
     return bb.used + 1024;
 }
 

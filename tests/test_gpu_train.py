@@ -303,3 +303,70 @@ def test_partial_save_and_recompute_give_the_same_gradients(kind, monkeypatch):
     split = [p.grad.clone() for p in m.parameters()] + ([] if film is None else [film.grad.clone()])
     for a, b in zip(results[0], split):
         assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(a.abs().max()))
+
+
+def test_film_parameter_optimisation_through_generator_render():
+    """pi_GAN/synthesis.py:83-107: GAN inversion optimises ONE image's FiLM parameters directly (a [9,512] leaf,
+    Adam lr 1e-4 there) through `generator.set_film_params(film_params); generator.render(0, 0)` and a second render at
+    a random pose.  Same loop here: through the reference-shaped calls (seeded jitter), and - with the jitter injected -
+    against the same loop on CPU autograd through the oracle: losses within 1 %, optimised FiLM parameters within 1e-3."""
+    from mirender import pigan, render_core
+    torch.manual_seed(0)
+    res, nc, nf = 12, 6, 12
+    gen = pigan.Generator(32, res, near=0.5, far=1.5, fov=12, coarse_samples=nc, fine_samples=nf).to(dev())
+    sd = synth.state_dict("film_siren_nerf", seed=40, sharp="medium")
+    gen.film_siren_nerf.load_state_dict(sd)
+    film0 = synth.film_params(2, seed=9)
+    pose0 = pigan.camera_pos_to_transform_matrix(1, 0, 0)
+    focal = gen.renderer.focal
+    rays0 = torch.from_numpy(R.rays_from_camera(res, res, focal, pose0))
+    tr = [synth.t_rand(res * res, nc, seed=700 + i) for i in range(8)]
+    with torch.no_grad():                                   # the image to invert: another FiLM table's render
+        f_t = ofields.make_field("film_siren_nerf", sd, film0[1])
+        target = R.render_rays(rays0, 0.5, 1.5, f_t, f_t, nc, nf, synth.t_rand(res * res, nc, seed=699)).rgb_f.reshape(res, res, 3)
+
+    # (a) the reference-shaped loop: set_film_params + render(0, 0) + render() at a NumPy-drawn pose
+    film = film0[0].clone().to(dev()).requires_grad_(True)           # synthesis.py:83-84
+    opt = torch.optim.Adam(params=[film], lr=3e-3)
+    np.random.seed(1)
+    losses = []
+    for step in range(8):
+        gen.set_film_params(film)
+        torch.manual_seed(step)
+        image = gen.render(0, 0)
+        rec = torch.mean((image - target.to(dev())) ** 2)
+        other = gen.render().mean()                                   # stand-in for the discriminator term
+        loss = 1e2 * rec + 0.1 * other
+        opt.zero_grad()
+        loss.backward()
+        assert film.grad is not None and bool(torch.isfinite(film.grad).all()) and float(film.grad.abs().max()) > 0
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.8 * losses[0], losses
+
+    # (b) the reconstruction term with injected jitter, HIP vs CPU autograd through the oracle
+    def run(hip):
+        film = (film0[0].clone().to(dev()) if hip else film0[0].clone()).requires_grad_(True)
+        opt = torch.optim.Adam(params=[film], lr=3e-3)
+        out = []
+        for step in range(8):
+            if hip:
+                gen.set_film_params(film)
+                image = render_core.render_image_tensor(res, res, focal, pose0, 0.5, 1.5, gen.film_siren_nerf,
+                                                        gen.film_siren_nerf, nc, nf, t_rand=tr[step].to(dev()))
+                loss = 1e2 * torch.mean((image - target.to(dev())) ** 2)
+            else:
+                f = ofields.make_field("film_siren_nerf", sd, film)
+                image = R.render_rays(rays0, 0.5, 1.5, f, f, nc, nf, tr[step]).rgb_f.reshape(res, res, 3)
+                loss = 1e2 * torch.mean((image - target) ** 2)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        return out, film.detach().cpu()
+    l_hip, f_hip = run(True)
+    l_cpu, f_cpu = run(False)
+    for a, b in zip(l_hip, l_cpu):
+        assert abs(a - b) <= 1e-2 * abs(b), (l_hip, l_cpu)
+    assert float((f_hip - f_cpu).norm() / (f_cpu - film0[0]).norm()) <= 2e-2       # relative to how far Adam moved them
+    assert float((f_hip - f_cpu).abs().max()) <= 1e-3
