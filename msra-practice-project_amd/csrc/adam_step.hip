@@ -68,6 +68,17 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamArgs a) {
     const PackTable& tb = c_bwd[a.kind[fld]];
     float* pf = a.packed_fwd[fld];
     float* pb = a.packed_bwd[fld];
+    // the items that hold this tensor, found once per block (a tensor sits in <= 10 forward and <= 9 transposed items;
+    // walking both 100-item tables per ELEMENT cost 130 us on a 1.2 M-parameter step)
+    __shared__ int hit_f[16], hit_b[16], n_hit[2];
+    if (threadIdx.x == 0) {
+        int nf = 0, nb = 0;
+        for (int i = 0; i < tf.n_items; ++i) if (tf.item[i].param == prm && nf < 16) hit_f[nf++] = i;
+        if (pb) for (int i = 0; i < tb.n_items; ++i) if (tb.item[i].param == prm && nb < 16) hit_b[nb++] = i;
+        n_hit[0] = nf; n_hit[1] = nb;
+    }
+    __syncthreads();
+    const int nf = n_hit[0], nb = n_hit[1];
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const float g = a.g[t][e];
         float m = a.m[t][e], v = a.v[t][e], p = a.p[t][e];
@@ -78,17 +89,14 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamArgs a) {
         p = p + a.step_size * (m / denom);                       // param.addcdiv_(exp_avg, denom, value = -lr / bc1)
         a.m[t][e] = m; a.v[t][e] = v; a.p[t][e] = p;
         const int row = e / in_f, col = e - row * in_f;
-        for (int i = 0; i < tf.n_items; ++i)
-            if (tf.item[i].param == prm) {
-                const int k = packed_index(tf.item[i], row, col);
-                if (k >= 0) pf[tf.dst_off[i] + k] = p;
-            }
-        if (pb)
-            for (int i = 0; i < tb.n_items; ++i)
-                if (tb.item[i].param == prm) {
-                    const int k = packed_index(tb.item[i], row, col);
-                    if (k >= 0) pb[tb.dst_off[i] + k] = p;
-                }
+        for (int h = 0; h < nf; ++h) {
+            const int i = hit_f[h], k = packed_index(tf.item[i], row, col);
+            if (k >= 0) pf[tf.dst_off[i] + k] = p;
+        }
+        for (int h = 0; h < nb; ++h) {
+            const int i = hit_b[h], k = packed_index(tb.item[i], row, col);
+            if (k >= 0) pb[tb.dst_off[i] + k] = p;
+        }
     }
 }
 

@@ -798,21 +798,32 @@ struct ReduceJob {
 struct ReduceBatch { ReduceJob job[kMaxReduceJobs]; };
 
 __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceBatch rb) {
-    // four consecutive record entries per thread (every record length and tile width is a multiple of 4): 16-byte
-    // loads, four partials in flight; the final sum order is fixed whatever the timing
+    // Block = 32 float4 entries x 8 k-lanes: lane g sums records g, g+8, g+16, ... (four 16-byte loads in flight), the
+    // eight lane sums are added in lane order through LDS - a fixed order whatever the timing.  A job's critical path
+    // is n/8 dependent-latency loads instead of n: the 128 x 256 GEMM of a NeRF's dir layer leaves 512 records
+    // (256 slabs x 2 k-splits), and with one thread walking all of them the whole launch waited 130 us for it.
+    __shared__ f32x4 part[8][32];
     const ReduceJob& j = rb.job[blockIdx.y];
-    const int idx = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (idx >= j.rec) return;
-    const f32x4* p = reinterpret_cast<const f32x4*>(j.src + idx);
-    const int64_t stride4 = j.rec / 4;
+    const int x = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int idx = (blockIdx.x * 32 + x) * 4;
+    const bool live = idx < j.rec;
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int k = 0;
-    for (; k + 4 <= j.n; k += 4) {
-        s0 += p[(int64_t)k * stride4]; s1 += p[(int64_t)(k + 1) * stride4];
-        s2 += p[(int64_t)(k + 2) * stride4]; s3 += p[(int64_t)(k + 3) * stride4];
+    if (live) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(j.src + idx);
+        const int64_t stride4 = j.rec / 4;
+        int k = g;
+        for (; k + 24 < j.n; k += 32) {
+            s0 += p[(int64_t)k * stride4]; s1 += p[(int64_t)(k + 8) * stride4];
+            s2 += p[(int64_t)(k + 16) * stride4]; s3 += p[(int64_t)(k + 24) * stride4];
+        }
+        for (; k < j.n; k += 8) s0 += p[(int64_t)k * stride4];
     }
-    for (; k < j.n; ++k) s0 += p[(int64_t)k * stride4];
-    const f32x4 s = (s0 + s1) + (s2 + s3);
+    part[g][x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g != 0 || !live) return;
+    f32x4 s = part[0][x];
+#pragma unroll
+    for (int t = 1; t < 8; ++t) s += part[t][x];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int e = idx + q;
@@ -1116,7 +1127,7 @@ struct BwdBatcher {
     }
     int reduce_all() {
         if (!partial || !n_red) return 0;
-        hipLaunchKernelGGL(reduce_jobs_kernel, dim3((max_rec / 4 + 255) / 256, n_red), dim3(256), 0, stream, all);
+        hipLaunchKernelGGL(reduce_jobs_kernel, dim3((max_rec / 4 + 31) / 32, n_red), dim3(256), 0, stream, all);
         return check_launch("reduce_jobs");
     }
 };
