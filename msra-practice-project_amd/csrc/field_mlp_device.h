@@ -109,15 +109,16 @@ __device__ __forceinline__ void issue_stage_slot(Ctx& c, int aux_slot, int chunk
 }
 
 // One row of fragments (all MB output blocks of one rg) is read first, then its 4*MB MFMAs are issued.
-// MFMA issue is in-order and blocking, so anything the wave issues in one lump between two MFMAs idles the
-// matrix pipe for its whole issue time (measured: 416 cycles for a lump of 8 DMA pieces, ~2.5 k cycles per
-// layer for the bias preload + activation lumps).  Everything else is therefore sliced and pinned between
-// MFMAs with sched_barrier:
+// Nothing overlaps an MFMA on this SIMD (tools/probes/mfma_valu_overlap.hip: every VALU / LDS / VMEM instruction between
+// two MFMAs adds its own issue time to the 64 cycles of the MFMA, with one wave per SIMD or with two), so the hooks
+// below do not hide work - they ORDER it: no lump delays a DMA piece or bunches row stores, and each piece of work sits
+// where its operands are ready:
 //   * slot(s), s = 0..MB-1: after every 4th MFMA of the first row - the next stage's DMA pieces;
-//   * ORDER bit 0 (a layer's first K block): the first row runs m-major and pre(m+1, part) - the bias preload
-//     of the NEXT accumulator block, a quarter at a time - sits after each MFMA of block m's chain;
-//   * ORDER bit 1 (a layer's last K block): the last row runs m-major and post(m-1, part) - the activation of
-//     the block whose chain has just completed - rides one MFMA behind (its result lands 64 cycles after issue).
+//   * ORDER bit 0 (a layer's first K block): the first row runs m-major and pre(m+1, part) - the start value of the
+//     NEXT accumulator block, a quarter at a time (K = 3 products; the backward chain's scaled head row) - sits after
+//     each MFMA of block m's chain;  ORDER bit 3: the chains start at zero, the first MFMA takes srcC = 0;
+//   * ORDER bit 1 (a layer's last K block): the last row runs m-major and post(m-1, part) - bias, activation and
+//     training stores of the block whose chain has just completed - follows one MFMA behind.
 // Other rows run q-major (MB independent accumulators round-robin); rows 1-3 offer mid(kb, s), s = 0..3MB-1, one
 // slot per 4 MFMAs, for global loads / stores that must not arrive in a burst (the training kernels' row traffic:
 // 32 x 1 KiB per wave in one 2048-cycle row saturates the CU's 64 B/clk vector-memory path).
@@ -294,7 +295,7 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 // A stage = up to two K blocks behind one barrier (39 barriers per NeRF tile instead of 77).  Stage buffers
 // alternate (c.buf); while stage i computes, stage i+1's pieces (or the next layer's aux pieces + its first
 // two K blocks: NEXT_AUX, NEXT_BLOCK = pieces of one of its K blocks, 0 for none) are DMA'd into the other one.
-// HOOKS: pre(m, part) / post(m, part) are the sliced bias preload / activation of mma_chunk; without them
+// HOOKS: pre(m, part) / post(m, part) are the sliced accumulator start / epilogue of mma_chunk; without them
 // init(acc) runs as one lump before the first MFMA and the caller applies its epilogue after the call.
 template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, bool HOOKS = false, bool ZERO_START = false,
           class Init, class BSel, class Pre = NoHook, class Post = NoHook, class Mid = NoHook>
@@ -338,9 +339,10 @@ struct SaveRows {
     bool valid;
 };
 
-// One forward layer with the bias preload and the activation (+ training stores) sliced between the MFMAs of
-// its first / last K block.  X <- act(W . [inputs] + b); the layer's inputs may be X itself (in place: block m
-// of X is rewritten only after every K block that reads it has been consumed).
+// One forward layer with its accumulator start (K = 3 products, else none: srcC = 0) and its epilogue (bias,
+// activation, training stores) sliced between the MFMAs of its first / last K block.  X <- act(W . [inputs] + b); the
+// layer's inputs may be X itself (in place: block m of X is rewritten only after every K block that reads it has been
+// consumed).
 // Training stores do not burst either: with DEFER_X this layer's X rows are written by the NEXT layer's mid slots
 // (slot 2(j%8)+1 of K block j/8 for quarter j; X is that layer's B operand and unchanged until its last row) - that
 // layer receives them as `prev` (PREV_MB blocks).  Sin layers save an ENCODING of X (cosine sign in the lowest bit)
