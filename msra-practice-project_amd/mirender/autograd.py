@@ -23,6 +23,29 @@ RESERVE_BYTES = CHUNK_BYTES + (16 << 30)   # what backward needs besides the kep
 #                                            + gradients (CHUNK_BYTES by construction), reduction scratch, raw / depths
 
 
+# MI_DEBUG_GUARDS=1 (tests/test_gpu_guards.py): every scratch / row buffer handed to the library gets GUARD extra floats of a
+# sentinel at its end, checked after the call - the library never allocates, so a kernel writing past what a *_floats()
+# query promised would otherwise corrupt a neighbouring tensor silently.
+GUARD = 4096
+_SENTINEL = 12345.678
+
+
+def _guarded(n: int, dev):
+    """torch.empty(n) fp32 on dev; with MI_DEBUG_GUARDS=1: (n + GUARD) with the tail set to the sentinel."""
+    import os
+    if os.environ.get("MI_DEBUG_GUARDS") != "1":
+        return torch.empty(int(n), dtype=torch.float32, device=dev), None
+    buf = torch.empty(int(n) + GUARD, dtype=torch.float32, device=dev)
+    buf[int(n):] = _SENTINEL
+    return buf[:int(n)], buf
+
+
+def _check_guard(whole, what: str):
+    if whole is not None and not bool((whole[-GUARD:] == _SENTINEL).all()):
+        bad = int((whole[-GUARD:] != _SENTINEL).nonzero()[-1]) + 1
+        raise _lib.MiRenderError(f"{what}: the library wrote {bad} floats past the end of the buffer")
+
+
 def _max_points_per_chunk(pf) -> int:
     lib = _lib.load()
     per_point = 4 * (lib.mi_field_train_acts_floats(pf.kind) + lib.mi_field_train_grads_floats(pf.kind))
@@ -45,12 +68,13 @@ def _forward_saving(pf: fields.PackedField, rays, z, film):
     n, s = z.shape
     pts = n * s
     f, groups, rpg = _groups(pf, film, n)
-    acts = torch.empty(lib.mi_field_train_acts_floats(pf.kind) * pts, dtype=torch.float32, device=dev)
+    acts, acts_g = _guarded(lib.mi_field_train_acts_floats(pf.kind) * pts, dev)
     raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.mi_field_eval_rays_train(pf.kind, _lib.ptr(pf.refresh()), _lib.ptr(f), _lib.ptr(rays), _lib.ptr(z),
                                                 groups, rpg, s, _lib.ptr(raw), _lib.ptr(acts), _lib.stream_ptr(dev)),
                    "mi_field_eval_rays_train")
+    _check_guard(acts_g, "saved layer inputs (mi_field_train_acts_floats)")
     return raw, acts
 
 
@@ -145,8 +169,8 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
             acts_c, raw_c = saved.pop(k), raw[r0:r1]
         else:
             raw_c, acts_c = _forward_saving(pf, rays[r0:r1], z[r0:r1], f_c)
-        gws = torch.empty(grads_f * pts, dtype=torch.float32, device=dev)
-        part = torch.empty(lib.mi_field_bwd_partial_floats(pts), dtype=torch.float32, device=dev)
+        gws, gws_g = _guarded(grads_f * pts, dev)
+        part, part_g = _guarded(lib.mi_field_bwd_partial_floats(pts), dev)
         out = [torch.empty_like(p) for p in pf.params]
         arr = (ctypes.c_void_p * len(out))(*[t.data_ptr() for t in out])
         # FiLM kinds: d gamma = <W, dW_image> + b . db_image needs the parameters themselves
@@ -156,6 +180,8 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
                                              _lib.ptr(raw_c), _lib.ptr(g_raw[r0:r1]), ng, ppg, _lib.ptr(part),
                                              _lib.ptr(fp), arr, par, len(out), _lib.ptr(g_c), stream), "mi_field_backward")
         del acts_c
+        _check_guard(gws_g, "per-layer gradients (mi_field_train_grads_floats)")
+        _check_guard(part_g, "backward scratch (mi_field_bwd_partial_floats)")
         if f_all is not None and add_to_row:
             g_film[g0:g0 + 1] += g_c
         if total is None:

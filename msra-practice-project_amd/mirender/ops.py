@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 
 import numpy as np
 import torch
@@ -185,7 +186,14 @@ def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, 
         if tuple(t_rand.shape) != (n, n_coarse):
             raise _lib.MiRenderError(f"t_rand must be [{n},{n_coarse}]")
     outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ((n, 3), (n,), (n,), (n, 3), (n,), (n,))]
-    ws = _Workspace.get(dev, lib.mi_render_workspace_bytes(n, n_coarse, n_fine))
+    ws_bytes = lib.mi_render_workspace_bytes(n, n_coarse, n_fine)
+    guard = None
+    if os.environ.get("MI_DEBUG_GUARDS") == "1":       # sentinel zone behind the workspace, checked after the call
+        ws = torch.empty(int(ws_bytes) + 16384, dtype=torch.uint8, device=dev)
+        ws[int(ws_bytes):] = 0xA5
+        guard = ws[int(ws_bytes):]
+    else:
+        ws = _Workspace.get(dev, ws_bytes)
     zl = linspace_table(near, far, n_coarse, dev) if exact_linspace else None
     ul = linspace_table(0.0, 1.0, n_fine, dev) if exact_linspace else None
     with torch.cuda.device(dev):
@@ -194,4 +202,6 @@ def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, 
                                       n_coarse, n_fine, _lib.ptr(zl), _lib.ptr(ul), _lib.ptr(t_rand),
                                       int(seed) & (2 ** 64 - 1), int(ray0), *[_lib.ptr(o) for o in outs], _lib.ptr(ws),
                                       _lib.stream_ptr(dev)), "mi_render_rays")
+    if guard is not None and not bool((guard == 0xA5).all()):
+        raise _lib.MiRenderError("mi_render_rays wrote past mi_render_workspace_bytes")
     return tuple(outs)
