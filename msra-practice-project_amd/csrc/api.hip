@@ -14,6 +14,7 @@ static thread_local char g_err[512] = "";
 static thread_local hipEvent_t g_mlp_ev[4] = {nullptr, nullptr, nullptr, nullptr};
 #ifdef MI_PROFILE_STAMPS
 static unsigned long long* g_stamps = nullptr;
+extern unsigned long long* g_bwd_stamps;          // field_mlp_bwd.hip
 #endif
 
 void set_error(const char* fmt, ...) {
@@ -251,7 +252,7 @@ int mi_field_backward(int kind, const float* packed_bwd, const float* film, cons
 }
 
 #ifdef MI_PROFILE_STAMPS
-void mi_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
+void mi_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; g_bwd_stamps = (unsigned long long*)p; }
 #endif
 
 int64_t mi_image_metrics_workspace_floats(int images, int channels, int height, int width) {

@@ -93,7 +93,12 @@ struct BwdArgs {
     const float* film;
     float* film_partial;     // unused by the chain (kept so the argument block stays stable)
     int64_t points_per_group, tiles_per_group, n_tiles;
+    unsigned long long* stamps;   // diagnostic build (-DMI_PROFILE_STAMPS) only: [block][128] s_memtime values (MI_STAMP)
 };
+
+#ifdef MI_PROFILE_STAMPS
+unsigned long long* g_bwd_stamps = nullptr;       // set by mi_debug_set_stamps (api.hip), diagnostic build only
+#endif
 
 // dA = dX (.) relu'(H) with H the saved post-ReLU activation; stores dA rows and leaves them in X.
 template <int MB>
@@ -112,7 +117,7 @@ __device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
             o.z = hv.z > 0.f ? dX[m][4 * rg + 2] : 0.f;
             o.w = hv.w > 0.f ? dX[m][4 * rg + 3] : 0.f;
             X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
-            if (valid) drow[m * 8 + rg * 2] = o;
+            drow[m * 8 + rg * 2] = o;
         }
 }
 
@@ -123,6 +128,9 @@ __device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 //                   latency sits under ~1000 MFMAs instead of stalling the one resident wave per SIMD;
 //   post(m, part) : dA = dX (.) act'(saved), written to HBM and left in X as the next layer's B operand.
 // B operands come from bsel; when the last K block reads X[j] with j < MB-1 pass a copy (post overwrites X[j]).
+// Row stores are NOT guarded by `valid`: lanes past the end of a partial tile are clamped to its last point, compute what
+// that point's own lane computes and store the same bytes to the same address; a guard costs a saveexec / branch /
+// restore around every store and stalled the in-order wave for hundreds of cycles each (field_mlp_device.h:fwd_layer).
 enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2, EPI_FILM = 3 };
 
 // EPI_SIN / EPI_FILM: saved = the layer's X rows with the cosine's sign in the lowest mantissa bit; the derivative
@@ -179,14 +187,14 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
                 }
             } else if constexpr (j < PREV_MB * 4 && !(MI_DIAG_NOROWS & 2)) {
                 constexpr int m = j / 4, rg = j % 4;
-                if (valid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+                prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
 #else
             if constexpr ((slot & 1) == 0) {
                 if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
             } else if constexpr (j < PREV_MB * 4) {
                 constexpr int m = j / 4, rg = j % 4;
-                if (valid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+                prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
 #endif
         }
@@ -204,7 +212,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             if constexpr (EPI == EPI_FILM) X[m][4 * rg + q] = o[q] * g[q];
             else X[m][4 * rg + q] = o[q];
         }
-        if constexpr (!DEFER) { if (valid) drow[m * 8 + rg * 2] = o; }   // (kept in MI_DIAG_NOROWS: keeps the chain live)
+        if constexpr (!DEFER) drow[m * 8 + rg * 2] = o;       // (kept in MI_DIAG_NOROWS: keeps the chain live)
     };
     mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
                                                               NoHook{}, bsel, acc, pre, post, mid);
@@ -238,6 +246,7 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
     const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
+    MI_STAMP(a, 0);
 
     __syncthreads();                                        // head rows (and K block 0) have landed
     {   // dH_d = W_rgb^T d_pre_rgb   (128 features)
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
             }
     }
     relu_bwd_store<4>(acc, X, acts(TINY ? 6 : 11), grads(TINY ? 4 : 9), 128, p, valid, c.h);   // dA of the dir layer
+    MI_STAMP(a, 1);
 
     int slot = 0;
     if constexpr (!TINY) {
@@ -264,19 +274,33 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
         for (int m = 0; m < 4; ++m) Bd[m] = X[m];
         const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
         bwd_layer<4, 8, 1, 32, EPI_LINEAR, false, false, true, 0>(c, slot, 0, 0.f, sel_d, acc, X, nullptr, grads(8), 256, p, valid);
+        MI_STAMP(a, 2);
         slot ^= 1;
         // layers_dir[0]^T, plus the sigma head's contribution to dH8; dA7 = dH8 (.) [H8>0]
         bwd_layer<8, 8, 0, 32, EPI_RELU, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, acts(8), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
+        MI_STAMP(a, 3);
         slot ^= 1;
+#ifdef MI_PROFILE_STAMPS
+        if (a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;                     // rows of L7^T: 32..64
+#endif
         bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(7), grads(6), 256, p, valid, -1, 0, nullptr, grads(7), 256);  // L7^T
+#ifdef MI_PROFILE_STAMPS
+        if (c.rowst) { MI_ROW_STAMP(c); }
+        c.rowst = nullptr;
+#endif
+        MI_STAMP(a, 4);
         bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(6), grads(5), 256, p, valid, -1, 0, nullptr, grads(6), 256);  // L6^T
+        MI_STAMP(a, 5);
         bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(5), grads(4), 256, p, valid, -1, 0, nullptr, grads(5), 256);  // L5^T (h part)
+        MI_STAMP(a, 6);
 #pragma unroll 1
         for (int l = 4; l >= 2; --l)                                                           // L4^T .. L2^T
             bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
                                                                     a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, -1, 0, nullptr,
                                                                     a.grads + (int64_t)(256 * l) * P, 256);
+        MI_STAMP(a, 7);                                                                        // after L4^T .. L2^T
         bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
+        MI_STAMP(a, 8);
     } else {
         // dir layer^T with the sigma head's contribution to dH4 (sigma row is aux piece 3 of slot 0)
         f32x16 Bd[4];
@@ -305,7 +329,7 @@ __device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)
             o.x = dsin30_from_saved(xv.x) * dX[m][4 * rg + 0]; o.y = dsin30_from_saved(xv.y) * dX[m][4 * rg + 1];
             o.z = dsin30_from_saved(xv.z) * dX[m][4 * rg + 2]; o.w = dsin30_from_saved(xv.w) * dX[m][4 * rg + 3];
             X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
-            if (valid) drow[m * 8 + rg * 2] = o;
+            drow[m * 8 + rg * 2] = o;
         }
 }
 
@@ -394,7 +418,7 @@ __device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
                 du[q] = dsin30_from_saved(cv[q]) * dX[m][4 * rg + q];
                 X[m][4 * rg + q] = du[q] * gv[q];
             }
-            if (valid) drow[m * 8 + rg * 2] = du;
+            drow[m * 8 + rg * 2] = du;
         }
 }
 
@@ -433,7 +457,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSe
         }
         if constexpr (kb < 4 && slot < 16 && (slot & 1) == 0) {
             constexpr int idx = (j / 4) * 8 + (j % 4) * 2;
-            if constexpr (STORE_PREV) { if (valid) prow[idx] = ring[j]; }
+            if constexpr (STORE_PREV) prow[idx] = ring[j];
             ring[j] = srow[idx];
         }
     };
@@ -447,7 +471,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSe
             X[m][4 * rg + q] = o[q] * g[q];
         }
         if constexpr (KEEP) ring[j] = o;
-        else { if (valid) drow[m * 8 + rg * 2] = o; }
+        else drow[m * 8 + rg * 2] = o;
     };
     mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true>(c, issue_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
 }
@@ -1204,7 +1228,12 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
     });
     if (arc) return arc;
     const int64_t tpg = (points_per_group + 127) / 128;
-    BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P, film, film_partial, points_per_group, tpg, n_groups * tpg};
+#ifdef MI_PROFILE_STAMPS
+    unsigned long long* stamps = g_bwd_stamps;
+#else
+    unsigned long long* stamps = nullptr;
+#endif
+    BwdArgs a{packed_bwd, acts, grads, raw, g_raw, P, film, film_partial, points_per_group, tpg, n_groups * tpg, stamps};
     const unsigned blocks = (unsigned)((kind == 2 || kind == 3) ? n_groups * tpg : (P + 127) / 128);
     int rc;
     if (kind == 0 || kind == 1 || kind == 4) {

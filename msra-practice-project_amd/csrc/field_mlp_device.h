@@ -283,7 +283,7 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
                 X[m][4 * rg + q] = sc.s;
                 xo[q] = sc.saved;
             }
-            if (valid) xrow[m * 8 + rg * 2] = xo;
+            xrow[m * 8 + rg * 2] = xo;                   // unguarded on purpose: see fwd_layer
         }
     }
 }
@@ -418,7 +418,11 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
         }
         if constexpr (SAVE && (kSinAct || !DEFER_X)) {
             // float4 index m*8 + rg*2 inside the row (h folded into the row pointer)
-            if (sv.valid) reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[m * 8 + rg * 2] = xo;
+            // NOT guarded by sv.valid: lanes past the end of a partial tile are clamped to its last point, compute
+            // exactly what that point's own lane computes and store the same bytes to the same address - while a
+            // guard costs a saveexec / branch / restore around every row store, and each of those branches cost the
+            // in-order wave hundreds of cycles (stamped profile of the chain: 2048-cycle rows took up to 5400)
+            reinterpret_cast<f32x4*>(sv.x + sv.p * sv.ld + 4 * h)[m * 8 + rg * 2] = xo;
         }
     };
     if constexpr (SAVE && PREV_MB > 0) {
@@ -426,12 +430,11 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
         constexpr int PPC = MB >= 8 ? 8 : 4;
         static_assert(KB * PPC >= PREV_MB * 4, "not enough K blocks to carry the previous layer's row quarters");
         f32x4* prow = reinterpret_cast<f32x4*>(prev.x + prev.p * prev.ld + 4 * h);
-        const bool pvalid = prev.valid && prev.x != nullptr;
         const auto mid = [&](auto kbc, auto sc) {
             constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * PPC + slot / 2;
             if constexpr (slot < 2 * PPC && (slot & 1) == 1 && j < PREV_MB * 4) {
                 constexpr int m = j / 4, rg = j % 4;
-                if (pvalid) prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+                prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
         };
         mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
