@@ -174,11 +174,31 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
     static_assert(!(EPI == EPI_SIN || EPI == EPI_FILM) || KB >= 5, "sin rows are decoded one K block after their load");
     const auto mid = [&](auto kbc, auto sc) {
         constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
+        if constexpr (KB == 8) {
+            // 8 K blocks: the row traffic is spread over the whole layer (tools/probes/mfma_store_mix.hip: 8 + 8 quarters
+            // per K block from every CU at once run into the memory system's mixed read/write ceiling, half that
+            // density costs a quarter as much).  Loads: slots 0, 4, .., 20 of K blocks 0..5, decoded one K block
+            // later; deferred stores: slots 2, 6, 10, 14 of K blocks 0..7.
+            if constexpr ((slot & 3) == 0) {
+                constexpr int jl = kb * 6 + slot / 4;
+                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 1 && kb <= 6 && jl - 6 < MB * 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sv[jl - 6][q] = dsin30_from_saved(sv[jl - 6][q]);
+                }
+                if constexpr (EPI != EPI_LINEAR && kb < 6 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+            } else if constexpr ((slot & 3) == 2 && slot < 16) {
+                constexpr int js = kb * 4 + slot / 4;
+                if constexpr (js < PREV_MB * 4) {
+                    constexpr int m = js / 4, rg = js % 4;
+                    prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+                }
+            }
+        } else
         if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 1 && kb < 5 && slot < 16 && (slot & 1) == 0 && j - 8 < MB * 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[j - 8][q] = dsin30_from_saved(sv[j - 8][q]);
         }
-        if constexpr (kb < 4 && slot < 16) {
+        if constexpr (KB != 8 && kb < 4 && slot < 16) {
 #ifdef MI_DIAG_NOROWS      // diagnostic builds only (tools/diag_build.sh): 1 = no row loads, 2 = no deferred row stores, 3 = neither
             if constexpr ((slot & 1) == 0) {
                 if constexpr (EPI != EPI_LINEAR && j < MB * 4) {
@@ -425,7 +445,7 @@ __device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X
 // One FiLM chain layer (bwd_layer's EPI_FILM case) whose dL/du rows do not burst out of the last row either: FiLM
 // layers carry gamma (.) dL/du in X, so X cannot be stored later as dA can; instead the epilogue parks each dL/du
 // quarter in the register that held its C quarter (`ring`, owned by the kernel), and the NEXT layer's mid slot
-// 2(j%8) of K block j/8 stores it right before loading its own saved-X quarter into the same register (decoded to
+// 4(j%6) of K block j/6 stores it right before loading its own saved-X quarter into the same register (decoded to
 // C = 30 cos(30 u) one K block later, see bwd_layer).
 //   STORE_PREV: ring holds the previous layer's dL/du (-> prev_dU);  KEEP: leave this layer's dL/du in ring
 //   (the caller's next layer stores it) instead of storing it from the epilogue.
@@ -450,15 +470,18 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSe
         }
     };
     const auto mid = [&](auto kbc, auto sc) {
-        constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
-        if constexpr (kb >= 1 && kb < 5 && slot < 16 && (slot & 1) == 0) {       // the quarter loaded one K block ago
+        // spread over the layer like bwd_layer's: quarter j = 6 kb + slot / 4 in slots 0, 4, .., 20 of K blocks 0..5
+        constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 6 + slot / 4;
+        if constexpr ((slot & 3) == 0) {
+            if constexpr (kb >= 1 && kb <= 6 && j - 6 < 32) {                    // the quarter loaded one K block ago
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ring[j - 8][q] = dsin30_from_saved(ring[j - 8][q]);
-        }
-        if constexpr (kb < 4 && slot < 16 && (slot & 1) == 0) {
-            constexpr int idx = (j / 4) * 8 + (j % 4) * 2;
-            if constexpr (STORE_PREV) prow[idx] = ring[j];
-            ring[j] = srow[idx];
+                for (int q = 0; q < 4; ++q) ring[j - 6][q] = dsin30_from_saved(ring[j - 6][q]);
+            }
+            if constexpr (kb < 6 && j < 32) {
+                constexpr int idx = (j / 4) * 8 + (j % 4) * 2;
+                if constexpr (STORE_PREV) prow[idx] = ring[j];
+                ring[j] = srow[idx];
+            }
         }
     };
     const auto post = [&](auto mc, auto pc) {
