@@ -132,18 +132,26 @@ template <int MB, int ORDER, int KBI = 0, class Slot, class Pre, class Post, cla
 __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x16& b, f32x16 (&acc)[8], Slot slot,
                                           Pre pre, Post post, Mid mid = Mid{}) {
     const f32x4* a4 = reinterpret_cast<const f32x4*>(chunk) + c.lane;
+    // Rows whose hooks are fenced with sched_barriers keep the compiler from starting the next row's operand reads
+    // early, and the row's first MFMA then waits a full LDS latency (tools/probes/mfma_store_mix.hip: ~90 cycles per
+    // 2048-cycle row).  Reading only the FIRST operand of the next row a few MFMAs ahead hides nearly all of it
+    // for 4 registers; the other reads follow at the row start, behind that MFMA.
+    f32x4 a_first = a4[0];
     static_for<4>([&](auto rgc) {
         constexpr int rg = decltype(rgc)::value;
         MI_ROW_STAMP(c);
         f32x4 a[MB];
+        a[0] = a_first;
 #pragma unroll
-        for (int m = 0; m < MB; ++m) a[m] = a4[(rg * MB + m) * 64];
+        for (int m = 1; m < MB; ++m) a[m] = a4[(rg * MB + m) * 64];
         constexpr bool first_mm = (ORDER & 1) && rg == 0;
         constexpr bool last_mm = (ORDER & 2) && rg == 3;
+        const auto ahead = [&]() { if constexpr (rg < 3) a_first = a4[((rg + 1) * MB) * 64]; };
         if constexpr (first_mm || last_mm) {
             if constexpr (first_mm) static_for<4>([&](auto pc) { pre(ic<0>{}, pc); });
             static_for<MB>([&](auto mc) {
                 constexpr int m = decltype(mc)::value;
+                if constexpr (m == (MB >= 2 ? MB - 2 : 0)) ahead();
                 static_for<4>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
                     if constexpr (first_mm && q == 0 && (ORDER & 8)) {
@@ -172,6 +180,7 @@ __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x
                 constexpr int q = decltype(qc)::value;
                 static_for<MB / 4>([&](auto gc) {
                     constexpr int g = decltype(gc)::value;
+                    if constexpr (q == 3 && g == 0) ahead();
 #pragma unroll
                     for (int m = 4 * g; m < 4 * g + 4; ++m)
                         acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][q], b[4 * rg + q], acc[m], 0, 0, 0);
@@ -427,12 +436,15 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     };
     if constexpr (SAVE && PREV_MB > 0) {
         // a K block offers 3 * MB mid slots (2 * MB in the layer's last one): PPC quarters per K block on its odd slots
-        constexpr int PPC = MB >= 8 ? 8 : 4;
+        // (as thinly as the layer's K blocks allow: every fourth slot when 4 quarters per K block are enough - the row
+        // traffic of all CUs arrives in phase, see tools/probes/mfma_store_mix.hip)
+        constexpr int PPC = MB >= 8 && KB * 4 < PREV_MB * 4 ? 8 : 4;
+        constexpr int STRIDE = MB >= 8 && PPC == 4 ? 4 : 2;
         static_assert(KB * PPC >= PREV_MB * 4, "not enough K blocks to carry the previous layer's row quarters");
         f32x4* prow = reinterpret_cast<f32x4*>(prev.x + prev.p * prev.ld + 4 * h);
         const auto mid = [&](auto kbc, auto sc) {
-            constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * PPC + slot / 2;
-            if constexpr (slot < 2 * PPC && (slot & 1) == 1 && j < PREV_MB * 4) {
+            constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * PPC + slot / STRIDE;
+            if constexpr (slot < STRIDE * PPC && slot % STRIDE == 1 && j < PREV_MB * 4) {
                 constexpr int m = j / 4, rg = j % 4;
                 prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }

@@ -14,7 +14,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDS_PTR __attribute__((address_space(3)))
 
-enum { ST = 1, LD = 2, BAR = 4, DS = 8, DMA = 16 };
+enum { ST = 1, LD = 2, BAR = 4, DS = 8, DMA = 16, DSP = 32, DSP2 = 64 };
 
 template <int F, int MODE = 0, int PH = 0>
 __global__ __launch_bounds__(256, 1) void k(float* rows_out, const float* rows_in, const float* wts, float* out, int iters) {
@@ -37,13 +37,18 @@ __global__ __launch_bounds__(256, 1) void k(float* rows_out, const float* rows_i
         float* to = tile_o + (size_t)it * tile_floats + row_off;
         const float* ti = tile_i + (size_t)it * tile_floats + row_off;
         const int q0 = (it & 3) * 8;                             // 32 quarters per layer = 4 K blocks x 8
-        f32x4 got[8] = {};                                          // consumed after the K block, like the chain's saved rows
+        f32x4 got[8] = {};
+        f32x4 nxt[4];
+        if (F & DSP) for (int t = 0; t < 4; ++t) nxt[t] = *reinterpret_cast<const f32x4*>(smem + t * 256 + lane * 4);                                          // consumed after the K block, like the chain's saved rows
 #pragma unroll
         for (int row = 0; row < 4; ++row) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {                        // 16 MFMAs per group
                 f32x4 a4[4];
-                if (F & DS) {
+                if (F & DSP) {                                   // operands read one group ahead (8 MFMAs before the group ends)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a4[t] = nxt[t];
+                } else if (F & DS) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
                         a4[t] = *reinterpret_cast<const f32x4*>(smem + ((row * 2 + g) * 4 + t) * 256 + lane * 4);
@@ -53,6 +58,18 @@ __global__ __launch_bounds__(256, 1) void k(float* rows_out, const float* rows_i
                 }
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
+                    if ((F & DSP) && j == 8) {
+                        constexpr int NP = (F & DSP2) ? 1 : 4;   // DSP2: only the first operand ahead, the rest at the group start
+#pragma unroll
+                        for (int t = 0; t < NP; ++t)
+                            nxt[t] = *reinterpret_cast<const f32x4*>(smem + (((row * 2 + g + 1) & 7) * 4 + t) * 256 + lane * 4);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if ((F & DSP2) && j == 0) {
+#pragma unroll
+                        for (int t = 1; t < 4; ++t)
+                            a4[t] = *reinterpret_cast<const f32x4*>(smem + ((row * 2 + g) * 4 + t) * 256 + lane * 4);
+                    }
                     acc[j & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j >> 2][j & 3], b, acc[j & 7], 0, 0, 0);
                     if ((j & 3) == 3) {
                         const int slot = g * 4 + (j >> 2);       // 0..7 within the row
@@ -143,6 +160,10 @@ int main() {
     run<ST | BAR>("ST BAR");
     run<ST | LD | BAR>("ST LD BAR");
     run<DS>("DS");
+    run<DS | DSP>("DS, operands one group ahead");
+    run<DS | DSP | DSP2>("DS, first operand ahead only");
+    run<DS | DSP | BAR>("DS ahead, BAR");
+    run<DS | DSP | DMA | ST | LD | BAR, 0, 3>("chain half density, DS ahead");
     run<DS | ST>("DS ST");
     run<DS | BAR>("DS BAR");
     run<DS | ST | LD | BAR>("DS ST LD BAR");
