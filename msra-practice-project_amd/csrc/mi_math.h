@@ -85,8 +85,9 @@ __device__ __forceinline__ SinSaved hw_sin30_saved(float u) {
 __device__ __forceinline__ float dsin30_from_saved(float xs) {
     // 900 (1 - X^2); |X| <= 1 makes it non-negative, and the |.| (a free source modifier of v_sqrt) keeps a
     // transcendental-unit result one ulp above 1 from turning into a NaN
+    // (the root is non-negative, so the sign goes in with an OR: one v_lshl_or_b32 instead of a shift and an xor)
     const float y = fmaf(xs * -900.f, xs, 900.f);
-    return __uint_as_float(__float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y))) ^ (__float_as_uint(xs) << 31));
+    return __uint_as_float((__float_as_uint(xs) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y))));
 }
 struct SinSaved2 { f32x2 s, saved; };
 __device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {

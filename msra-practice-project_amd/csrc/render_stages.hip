@@ -229,11 +229,67 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n, int S, co
 }
 
 // ---------------------------------------------------------------------------------------
+// cdf[j] = fp32(sum_{i<j} pdf[i]) with the running sum in fp64, j = 0..nb-1, pdf[0..nb-2] in LDS: ATen's CPU cumsum
+// keeps the running sum in the accumulate type of float, i.e. DOUBLE, and rounds every output to fp32
+// (cpu_cum_base_kernel).  A double holds every partial sum of these floats EXACTLY whenever the terms' exponents span
+// few enough bits (largest sum's exponent - smallest term's last mantissa bit <= 52), and exact sums do not depend
+// on the order of the additions: the wave then takes a shuffle scan (6 steps) instead of nb dependent additions.
+// Terms that do not qualify (inf / NaN, or a dynamic range beyond 2^(28 - log2 nb)) take the sequential order itself.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void cdf_like_cumsum(const float* pdf, float* cdf, int nb, int lane) {
+    const int nw = nb - 1;
+    int fmin = 255, fmax = 0;
+    for (int j = lane; j < nw; j += 64) {
+        const int f = (int)((__float_as_uint(pdf[j]) >> 23) & 0xffu);
+        const bool zero = (__float_as_uint(pdf[j]) << 1) == 0u;
+        fmax = f > fmax ? f : fmax;
+        if (!zero) { const int g = f > 1 ? f : 1; fmin = g < fmin ? g : fmin; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int a = __shfl_xor(fmin, o), b = __shfl_xor(fmax, o);
+        fmin = a < fmin ? a : fmin;
+        fmax = b > fmax ? b : fmax;
+    }
+    const int log2n = 32 - __builtin_clz((unsigned)(nb > 1 ? nb - 1 : 1));
+    const bool exact = fmax < 255 && (fmin > fmax || fmax - fmin <= 28 - log2n);
+    if (exact) {
+        double carry = 0.0;
+        for (int base = 0; base < nb; base += 64) {
+            const int j = base + lane;
+            double incl = j < nw ? (double)pdf[j] : 0.0;
+            const double own = incl;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double up = __shfl_up(incl, o);
+                if (lane >= o) incl += up;
+            }
+            if (j < nb) cdf[j] = (float)(carry + (incl - own));      // exclusive prefix (exact, like every sum here)
+            carry += __shfl(incl, 63);
+        }
+    } else {
+        for (int j = lane; j < nb; j += 64) {
+            double sum = 0.0;
+            for (int i = 0; i < j; ++i) sum += (double)pdf[i];
+            cdf[j] = (float)sum;
+        }
+    }
+}
+
+// (value, index) as one unsigned key: float order for everything that is not a NaN (with -0 before +0), ties by
+// index - the rank sort below then needs one 64-bit compare per pair instead of two float compares and an index test
+__device__ __forceinline__ uint64_t sort_key(float v, int i) {
+    uint32_t b = __float_as_uint(v);
+    b ^= (b >> 31) ? 0xffffffffu : 0x80000000u;
+    return ((uint64_t)b << 32) | (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------
 // sample_fine: one wave per ray.  bins = mids of the coarse linspace, w = weights[1:-1]+1e-5,
 // pdf = w/sum(w), cdf = [0, cumsum(pdf)] with the running sum in fp64 rounded per entry like
 // torch.cumsum on CPU; u = linspace(0,1,Nf); idx = #(cdf <= u) (searchsorted right=True); guarded lerp;
-// then z_fine = sort(cat(z_coarse, z_samples)) by full rank counting (no sortedness assumed).
-// LDS per wave: cdf[Nc] | bins[Nc] | zall[Nc+Nf]
+// then z_fine = sort(cat(z_coarse, z_samples)) by full rank counting (no sortedness assumed; -0 ranks before +0).
+// LDS per wave: cdf[Nc] | bins[Nc] | zall[Nc+Nf] | zout[Nc+Nf] (the sorted row, stored coalesced)
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_, float far_, int nc, int nf,
                                                           const float* __restrict__ z_lin,
@@ -244,10 +300,11 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = nc + nf;
-    const int per_wave = 2 * nc + S;
+    const int per_wave = 2 * nc + 2 * S;
     float* cdf = smem + wave * per_wave;
     float* bins = cdf + nc;
     float* zall = bins + nc;
+    float* zout = zall + S;
     const int nb = nc - 1;      // bins / cdf entries
     const int nw = nc - 2;      // interior weights
     auto lin = [&](int i) { return z_lin ? z_lin[i] : linspace_at(near_, far_, nc, i); };
@@ -266,13 +323,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
         for (int j = lane; j < nw; j += 64) zall[j] = (wr[j + 1] + 1e-5f) / total;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // ATen's CPU cumsum keeps the running sum in the accumulate type of float, i.e. DOUBLE, and rounds
-        // every output to fp32 (cpu_cum_base_kernel): do the same so the cdf matches bit for bit.
-        for (int j = lane; j < nb; j += 64) {
-            double s = 0.0;
-            for (int i = 0; i < j; ++i) s += (double)zall[i];
-            cdf[j] = (float)s;
-        }
+        cdf_like_cumsum(zall, cdf, nb, lane);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // coarse depths first, then inverse-CDF samples
@@ -298,16 +349,47 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // rank sort: position = #(smaller) + #(equal with lower index)
-        for (int e = lane; e < S; e += 64) {
-            const float v = zall[e];
-            int rank = 0;
-            for (int i = 0; i < S; ++i) {
-                const float o = zall[i];
-                rank += (o < v) || (o == v && i < e);
+        // Merge by rank: position of an element = #(keys below its own), key = (value, index).  Both lists are
+        // sorted on every call the render path makes (stratified depths; inverse-CDF samples of an ascending u), and
+        // then a rank is the element's own index in its list plus one binary search in the other list.  A ray whose
+        // lists are not sorted (the stage-level entry point takes any depths) is ranked by full counting instead.
+        bool sorted = true;
+        for (int e = lane; e + 1 < S; e += 64)
+            if (e + 1 != nc) sorted = sorted && !(zall[e + 1] < zall[e]) && zall[e] == zall[e] && zall[e + 1] == zall[e + 1];
+        if (__builtin_amdgcn_ballot_w64(!sorted) == 0ull) {
+            for (int e = lane; e < S; e += 64) {
+                const float v = zall[e];
+                const bool coarse = e < nc;
+                // coarse element: #(samples < v) (an equal sample has the higher index); sample: #(coarse <= v)
+                const float* other = coarse ? zall + nc : zall;
+                int lo_i = 0, hi_i = coarse ? nf : nc;
+                while (lo_i < hi_i) {
+                    const int mid = (lo_i + hi_i) >> 1;
+                    const float o = other[mid];
+                    if (coarse ? o < v : o <= v) lo_i = mid + 1; else hi_i = mid;
+                }
+                zout[(coarse ? e : e - nc) + lo_i] = v;
             }
-            z_fine[ray * S + rank] = v;
+        } else {
+            for (int e0 = lane; e0 < S; e0 += 256) {                 // up to four elements per sweep over the list
+                uint64_t key[4];
+                int rank[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) key[k] = e0 + 64 * k < S ? sort_key(zall[e0 + 64 * k], e0 + 64 * k) : ~0ull;
+#pragma unroll 8
+                for (int i = 0; i < S; ++i) {
+                    const uint64_t o = sort_key(zall[i], i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) rank[k] += o < key[k] ? 1 : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (e0 + 64 * k < S) zout[rank[k]] = zall[e0 + 64 * k];
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int e = lane; e < S; e += 64) z_fine[ray * S + e] = zout[e];        // coalesced rows out of LDS
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
@@ -336,11 +418,7 @@ __global__ __launch_bounds__(256) void sample_pdf_kernel(int64_t n, int nb, int 
         for (int j = lane; j < nw; j += 64) pdf[j] = (wr[j] + 1e-5f) / part;
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (int j = lane; j < nb; j += 64) {
-            double s = 0.0;
-            for (int i = 0; i < j; ++i) s += (double)pdf[i];
-            cdf[j] = (float)s;
-        }
+        cdf_like_cumsum(pdf, cdf, nb, lane);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         for (int s = lane; s < ns; s += 64) {
@@ -432,8 +510,8 @@ int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const
                        const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
                        hipStream_t stream) {
     if (n <= 0) return 0;
-    const size_t lds = (size_t)4 * (2 * nc + nc + nf) * sizeof(float);
-    if (lds > 160 * 1024) { set_error("sample_fine: Nc=%d Nf=%d exceed LDS", nc, nf); return -1; }
+    const size_t lds = (size_t)4 * (2 * nc + 2 * (nc + nf)) * sizeof(float);
+    if (lds > 64 * 1024) { set_error("sample_fine: Nc=%d Nf=%d exceed LDS", nc, nf); return -1; }
     int64_t blocks = (n + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(sample_fine_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, n, near_, far_, nc, nf,

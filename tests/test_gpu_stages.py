@@ -238,6 +238,40 @@ def test_sample_fine_is_sorted_permutation(mi):
     assert torch.equal(zf, ref)                            # the merge is an exact sort of the same multiset
 
 
+def test_sample_pdf_cumsum_paths(mi):
+    """The cdf is ATen's cumsum (fp64 running sum, fp32 outputs).  The kernel takes a shuffle scan when every partial
+    sum is exact in a double and the sequential order otherwise: many bins (four 64-lane chunks with carries), weights
+    spanning 2^40 (sequential path) and ordinary weights must all land on the oracle's samples."""
+    gen = torch.Generator().manual_seed(11)
+    for case, nb, scale in (("200 bins", 200, None), ("range 2^40", 63, 40.0), ("range 2^40, 130 bins", 130, 40.0),
+                            ("ordinary", 63, None)):
+        n, ns = 64, 96
+        bins = torch.sort(torch.rand((n, nb), generator=gen) * 4 + 2, -1).values
+        w = torch.rand((n, nb - 1), generator=gen)
+        if scale is not None:
+            w = w * torch.exp2(torch.rand((n, nb - 1), generator=gen) * scale - 10)
+        ref = R.sample_pdf(bins, w, ns).numpy()
+        got = mi.ops.sample_pdf(to_dev(bins), to_dev(w), ns).cpu().numpy().astype(np.float64)
+        mask, tol = _pdf_conditioning(bins.numpy(), w.numpy(), ns)
+        d = np.abs(got - ref)
+        bad = (d > tol) & ~mask
+        parity.record(case=f"pdf cumsum paths/{case}", stage="sample_pdf", qty="samples", tol=1.0, active="hard",
+                      err_vs_oracle32=float((d / tol)[~mask].max(initial=0.0)), passed=not bad.any(),
+                      unit="multiples of the per-sample conditioning tolerance", exact_frac=float((d == 0).mean()))
+        assert not bad.any(), (case, d[bad].max())
+
+
+def test_sample_fine_sorts_signed_and_repeated_depths(mi):
+    """The merge ranks (value, index) keys: negative depths, repeated values and the coarse / fine lists in any order."""
+    n, nc, nf = 257, 16, 40
+    gen = torch.Generator().manual_seed(2)
+    zc = torch.round((torch.rand((n, nc), generator=gen) * 2 - 1) * 8) / 8          # unsorted, signed, many ties
+    w = torch.rand((n, nc), generator=gen)
+    zf, zs = mi.ops.sample_fine(to_dev(zc), to_dev(w), -1.0, 1.0, nf, want_samples=True)
+    ref = torch.sort(torch.cat([zc.to(dev()), zs], -1), -1).values
+    assert torch.equal(zf, ref)
+
+
 # ------------------------------------------------------------------ fused field MLP
 KINDS = ["nerf", "siren_nerf", "film_siren_nerf", "film_siren_nerf_nodir"]
 
