@@ -167,9 +167,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         if constexpr (SCALED) {
             const f32x4 w = pv[piece * 64 + m * 8 + rg];
             acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
-        } else {
-            acc[m][4 * rg + 0] = 0.f; acc[m][4 * rg + 1] = 0.f; acc[m][4 * rg + 2] = 0.f; acc[m][4 * rg + 3] = 0.f;
-        }
+        }       // else: nothing to write, the layer's first MFMAs take srcC = 0 (mma_layer_fn ZERO_START)
     };
     static_assert(!(EPI == EPI_SIN || EPI == EPI_FILM) || KB >= 5, "sin rows are decoded one K block after their load");
     const auto mid = [&](auto kbc, auto sc) {
@@ -234,8 +232,8 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         }
         if constexpr (!DEFER) drow[m * 8 + rg * 2] = o;       // (kept in MI_DIAG_NOROWS: keeps the chain live)
     };
-    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
-                                                              NoHook{}, bsel, acc, pre, post, mid);
+    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !SCALED>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
+                                                                       NoHook{}, bsel, acc, pre, post, mid);
 }
 
 // =========================================================================================
@@ -465,9 +463,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSe
         if constexpr (SCALED) {
             const f32x4 w = pv[piece * 64 + m * 8 + rg];
             acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
-        } else {
-            acc[m][4 * rg + 0] = 0.f; acc[m][4 * rg + 1] = 0.f; acc[m][4 * rg + 2] = 0.f; acc[m][4 * rg + 3] = 0.f;
-        }
+        }       // else: nothing to write, the layer's first MFMAs take srcC = 0 (mma_layer_fn ZERO_START)
     };
     const auto mid = [&](auto kbc, auto sc) {
         // spread over the layer like bwd_layer's: quarter j = 6 kb + slot / 4 in slots 0, 4, .., 20 of K blocks 0..5
@@ -496,7 +492,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSe
         if constexpr (KEEP) ring[j] = o;
         else drow[m * 8 + rg * 2] = o;
     };
-    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true>(c, issue_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
+    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true, !SCALED>(c, issue_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
 }
 
 template <bool USE_DIR>

@@ -7,6 +7,12 @@
 //   DS   8 ds_read_b128 per 16 MFMAs feeding the A operands
 //   DMA  8 x 1 KiB buffer_load ... lds per wave in row 0 (the next weight stage)
 // 4 waves per CU, 256 CUs, 32 K blocks per wave.  Prints cycles per K block (8192 = pure MFMA issue).
+// Findings (profiles/r02_probe_mfma_store_mix.log): 8 stores or 8 loads per K block alone cost 17 / 33 cycles apiece, both
+// together 80-110 apiece wherever they sit in the K block (every CU issues them at the same time: 4.9 TB/s of demand
+// against the 4.1-4.4 TB/s of mixed traffic the memory system delivers), half the density a quarter of that; nontemporal
+// hints make it far worse; reading the first A operand of a group ahead of time recovers about half of the LDS cost.
+// The combined variants overstate what the real kernels pay (their rows run at 2 200-2 400 cycles): use them for
+// differences, not for absolute numbers.
 // build: hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_store_mix.hip -o gpurun_tools/mfma_store_mix
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -74,9 +80,8 @@ __global__ __launch_bounds__(256, 1) void k(float* rows_out, const float* rows_i
                     if ((j & 3) == 3) {
                         const int slot = g * 4 + (j >> 2);       // 0..7 within the row
                         __builtin_amdgcn_sched_barrier(0);
-                        // PH 0: row traffic in every K block; 1: in K blocks 0-3 of every 8 (the chain), all CUs in phase; 2: the same
-                        // with the CUs' phases spread; 3: every K block at half density
-                        const bool on = PH == 0 ? true : PH == 1 ? (it & 7) < 4 : PH == 2 ? ((it + blockIdx.x) & 7) < 4 : slot < 4;
+                        // PH 0: 8 + 8 row instructions per K block; 3: half that density (the same bytes over twice the time)
+                        const bool on = PH == 0 ? true : slot < 4;
                         if ((row == 1 || row == 2) && on) {
                             // MODE 0: load / store alternate; 1: all loads in row 1, all stores in row 2; 2: per row, four loads
                             // then four stores; 3: as 0 with nontemporal stores; 4: as 0 with nontemporal loads and stores
@@ -150,11 +155,7 @@ int main() {
     run<ST | LD, 5>("ST LD, contiguous KiB quarters");
     run<ST | LD | BAR, 5>("ST LD BAR, contiguous");
     run<DS | DMA | ST | LD | BAR, 5>("DS DMA ST LD BAR, contiguous");
-    run<ST | LD, 0, 1>("ST LD, K blocks 0-3 of 8, in phase");
-    run<ST | LD, 0, 2>("ST LD, K blocks 0-3 of 8, phases spread");
     run<ST | LD, 0, 3>("ST LD, half density everywhere");
-    run<DS | DMA | ST | LD | BAR, 0, 1>("chain, K blocks 0-3 of 8, in phase");
-    run<DS | DMA | ST | LD | BAR, 0, 2>("chain, K blocks 0-3 of 8, phases spread");
     run<DS | DMA | ST | LD | BAR, 0, 3>("chain, half density everywhere");
     run<BAR>("BAR");
     run<ST | BAR>("ST BAR");

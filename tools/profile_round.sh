@@ -17,8 +17,8 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
     timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_$d -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-frame64 --no-train > gpurun_out/pmc_$d.log 2>&1 || exit 1
     echo "pmc $d ok"
 done
-# training workloads: kernel stats + HBM / MFMA-busy counters of one step each (C4 = pi_GAN generator step, nerf 1024-ray step)
-for wl in c4 nerf_train; do
+# training workloads: kernel stats + HBM / MFMA-busy counters of one step each (C4 / C5 = pi_GAN steps, nerf 1024-ray step)
+for wl in c4 c5 nerf_train; do
     rm -rf gpurun_out/prof_stats_$wl
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stats_$wl -- python3 bench.py --workload $wl --steps 3 --warmup 1 > gpurun_out/prof_stats_$wl.log 2>&1 || exit 1
     for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do

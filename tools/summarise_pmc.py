@@ -115,5 +115,5 @@ def train_summary(wl):
             print(f"{wl:10s} {name[:60]:60s} {row['ms']:9.2f} ms {row['hbm_GBps']:8.1f} GB/s  busy {row.get('mfma_busy_frac', float('nan')):.3f}")
 
 
-for wl in ("c4", "nerf_train"):
+for wl in ("c4", "c5", "nerf_train"):
     train_summary(wl)
