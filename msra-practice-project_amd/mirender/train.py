@@ -148,7 +148,7 @@ class FusedAdam:
     def _ensure_state(self):
         for p in self.params:
             if p not in self.state:
-                self.state[p] = dict(step=torch.tensor(float(self._step)), exp_avg=torch.zeros_like(p),
+                self.state[p] = dict(step=torch.tensor(float(self._step), device="cpu"), exp_avg=torch.zeros_like(p),
                                      exp_avg_sq=torch.zeros_like(p))
 
     @torch.no_grad()
@@ -156,6 +156,9 @@ class FusedAdam:
         lib = _lib.load()
         g = self.param_groups[0]
         lr, (beta1, beta2), eps = float(g["lr"]), g["betas"], float(g["eps"])
+        if g.get("weight_decay") or g.get("amsgrad") or g.get("maximize"):
+            raise _lib.MiRenderError("FusedAdam implements plain Adam (train_nerf.py:98): weight_decay / amsgrad / maximize "
+                                     "are not supported - use torch.optim.Adam for those")
         if any(p.grad is None for p in self.params):
             raise _lib.MiRenderError("FusedAdam.step: every parameter needs a gradient (run backward first)")
         self._ensure_state()

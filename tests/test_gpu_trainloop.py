@@ -208,6 +208,13 @@ def test_fused_adam_in_the_training_step(mi):
     assert losses["fused"][-1] < losses["fused"][0]
     m = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=62), dev())
     assert len(mi.train.FusedAdam([m, m]).fields) == 1
+    # options plain Adam does not have are refused, not ignored
+    opt = mi.train.FusedAdam(m)
+    opt.param_groups[0]["weight_decay"] = 1e-2
+    for p in m.parameters():
+        p.grad = torch.zeros_like(p)
+    with pytest.raises(mi.lib.MiRenderError):
+        opt.step()
 
 
 def test_ray_bank_float64_focal_and_reference_reshuffle_quirk(mi):
