@@ -13,16 +13,30 @@ namespace mi {
 //    |30 u| ~ 100 (first layers on raw coordinates) that rounding moves the sine by up to 4e-6, so reducing the exact
 //    product instead (as the first version of this file did) is closer to real arithmetic but 10x further from
 //    the reference than the transcendental unit's own error;
-//  * revolutions = t / (2 pi) as a two-float product, reduced to [-1/2, 1/2] (hi - rndne(hi) is exact, the low
-//    part is added to a value whose ulp is <= 3e-8) before v_sin.
+//  * revolutions = t / (2 pi) with 1 / (2 pi) as a two-float constant, reduced to [-1/2, 1/2] before v_sin:
+//    n = rndne(fl(t c_hi)), r = fma(t, c_lo, fma(t, c_hi, -n)) - four instructions.
 // Measured on MI355X (tools/probes/sin_variants.hip) against sin(fl(30 u)) in fp64 over |u| < 40: max abs error
-// 1.8e-7, rms 4.2e-8 (v_fract instead of the centred reduction: 4.2e-7 / 6.9e-8; libm sinf: 6.9e-8 / 1.8e-8), at
-// 8 instructions instead of libm's ~40 with a Payne-Hanek slow path at every call site.
+// 2.5e-7, rms 4.9e-8 (the six-instruction form hi = fl(t c_hi), lo = fma(t, c_lo, fma(t, c_hi, -hi)),
+// r = (hi - rndne(hi)) + lo that this replaced: 1.8e-7 / 4.2e-8; v_fract instead of the centred reduction:
+// 4.2e-7 / 6.9e-8; libm sinf: 6.9e-8 / 1.8e-8): two VALU instructions per activation are 1.5 % of a sin layer's time
+// (every instruction between two MFMAs costs its issue cycles), the 7e-9 of rms error is 1/20 of what the layer's
+// own 256-term fp32 dot product contributes.
 // hipcc contracts a*b-c into an fma ACROSS statements by default, which would replace the rounded `hi` below by the
 // exact product and count its low part twice: contraction is off inside these helpers.
-__device__ __forceinline__ float hw_turns(float t) {
+__device__ __forceinline__ float hw_turns_fast(float t) {
 #pragma clang fp contract(off)
     const float c_hi = 0.15915494309189535f;                                    // 1 / (2 pi)
+    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    // n = the nearest whole revolution of the ROUNDED product; both fmas then run against n: t c_hi - n with one
+    // rounding (the difference is small, so that rounding is at the result's own ulp), plus the constant's low part
+    const float n = rintf(t * c_hi);
+    return fmaf(t, c_lo, fmaf(t, c_hi, -n));
+}
+// The six-instruction form (1.8e-7 / 4.2e-8): kept for the positional encoding, which runs 84 times per POINT (not per
+// layer) and feeds an error-amplifying network - the NeRF field's closest parity case sits at 0.96 of its 1e-4 gate.
+__device__ __forceinline__ float hw_turns(float t) {
+#pragma clang fp contract(off)
+    const float c_hi = 0.15915494309189535f;
     const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
     const float hi = t * c_hi;
     const float lo = fmaf(t, c_lo, fmaf(t, c_hi, -hi));
@@ -30,7 +44,7 @@ __device__ __forceinline__ float hw_turns(float t) {
 }
 __device__ __forceinline__ float hw_turns30(float u) {
 #pragma clang fp contract(off)
-    return hw_turns(30.f * u);
+    return hw_turns_fast(30.f * u);
 }
 #if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1     // diagnostic builds only (tools/diag_build.sh): no activation work at all
 __device__ __forceinline__ float hw_sin30(float u) { return u; }
@@ -54,9 +68,8 @@ __device__ __forceinline__ f32x2 hw_turns_x2(f32x2 t) {
     const float cl = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
     const f32x2 c_lo = {cl, cl};
     const f32x2 hi = t * c_hi;
-    const f32x2 lo = __builtin_elementwise_fma(t, c_lo, __builtin_elementwise_fma(t, c_hi, -hi));
-    const f32x2 k = {rintf(hi.x), rintf(hi.y)};
-    return (hi - k) + lo;
+    const f32x2 n = {rintf(hi.x), rintf(hi.y)};
+    return __builtin_elementwise_fma(t, c_lo, __builtin_elementwise_fma(t, c_hi, -n));
 }
 __device__ __forceinline__ f32x2 hw_turns30_x2(f32x2 u) {
 #pragma clang fp contract(off)

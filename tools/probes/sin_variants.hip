@@ -6,26 +6,31 @@
 #include <stdlib.h>
 #include <vector>
 // t = fl(30 u) as torch.sin(30 * x) sees it; revolutions = t / (2 pi) as a two-float product (no contraction of hi)
-// hipcc contracts a*b-c into fma across statements by default (__fmul_rn is a plain *): the reductions below need
-// the ROUNDED product, so contraction is switched off for this file's arithmetic.
-#pragma clang fp contract(off)
+// hipcc contracts a*b-c into fma across statements by default, and __fmul_rn / __fsub_rn are header functions compiled
+// WITH contraction (their operations carry the flag wherever they are inlined): the reductions below need the ROUNDED
+// product, so they use plain operators inside bodies that switch contraction off.
+// (the pragma only takes effect INSIDE a function body)
+#define NO_CONTRACT _Pragma("clang fp contract(off)")
 __device__ __forceinline__ void two_prod(float u, float& hi, float& lo) {
+    NO_CONTRACT
     const float c_hi = 0.15915494309189535f;
     const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
-    const float t = __fmul_rn(30.f, u);
-    hi = __fmul_rn(t, c_hi);
+    const float t = (30.f * u);
+    hi = (t * c_hi);
     lo = fmaf(t, c_lo, fmaf(t, c_hi, -hi));
 }
-__device__ float v0(float u) { float hi, lo; two_prod(u, hi, lo); return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(hi) + lo); }
-__device__ float v1(float u) { float hi, lo; two_prod(u, hi, lo); return __builtin_amdgcn_sinf(__fadd_rn(__fsub_rn(hi, rintf(hi)), lo)); }
+__device__ float v0(float u) { NO_CONTRACT float hi, lo; two_prod(u, hi, lo); return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(hi) + lo); }
+__device__ float v1(float u) { NO_CONTRACT float hi, lo; two_prod(u, hi, lo); return __builtin_amdgcn_sinf(((hi - rintf(hi)) + lo)); }
 __device__ float v2(float u) {
+    NO_CONTRACT
     float hi, lo; two_prod(u, hi, lo);
-    const float r = __fadd_rn(__fsub_rn(hi, rintf(hi)), lo);
+    const float r = ((hi - rintf(hi)) + lo);
     return __builtin_amdgcn_sinf(__builtin_amdgcn_fmed3f(r, 0.5f - r, -0.5f - r));
 }
 __device__ float v3(float u) {   // fold + polynomial for sin(2 pi r), |r| <= 1/4
+    NO_CONTRACT
     float hi, lo; two_prod(u, hi, lo);
-    float r = __fadd_rn(__fsub_rn(hi, rintf(hi)), lo);
+    float r = ((hi - rintf(hi)) + lo);
     r = __builtin_amdgcn_fmed3f(r, 0.5f - r, -0.5f - r);
     const float s = r * r;
     float p = fmaf(s, 39.76049716f, -76.58125642f);      // least-squares fit on Chebyshev nodes: 6.7e-9 max error
@@ -35,13 +40,21 @@ __device__ float v3(float u) {   // fold + polynomial for sin(2 pi r), |r| <= 1/
     return p * r;
 }
 __device__ float v4(float u) { return sinf(30.f * u); }   // libm on the product rounded to fp32 (what torch.sin(30*x) sees)
+__device__ float v5(float u) {   // n from the rounded product, both fmas against n: mul, rndne, fma, fma (4 instead of 6)
+    NO_CONTRACT
+    const float c_hi = 0.15915494309189535f;
+    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    const float t = (30.f * u);
+    const float n = rintf((t * c_hi));
+    return __builtin_amdgcn_sinf(fmaf(t, c_lo, fmaf(t, c_hi, -n)));
+}
 __global__ void run(const float* u, float* o, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    o[0 * n + i] = v0(u[i]); o[1 * n + i] = v1(u[i]); o[2 * n + i] = v2(u[i]); o[3 * n + i] = v3(u[i]); o[4 * n + i] = v4(u[i]);
+    o[0 * n + i] = v0(u[i]); o[1 * n + i] = v1(u[i]); o[2 * n + i] = v2(u[i]); o[3 * n + i] = v3(u[i]); o[4 * n + i] = v4(u[i]); o[5 * n + i] = v5(u[i]);
 }
 int main() {
-    const int n = 1 << 22, nv = 5;
+    const int n = 1 << 22, nv = 6;
     std::vector<float> u(n), o((size_t)nv * n);
     srand(1);
     for (int i = 0; i < n; ++i) u[i] = (float)((rand() / (double)RAND_MAX * 2 - 1) * (i % 4 == 0 ? 40.0 : i % 4 == 1 ? 4.0 : i % 4 == 2 ? 0.5 : 0.05));
@@ -50,7 +63,7 @@ int main() {
     (void)hipMemcpy(du, u.data(), n * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(run, dim3(n / 256), dim3(256), 0, 0, du, dout, n);
     (void)hipMemcpy(o.data(), dout, (size_t)nv * n * 4, hipMemcpyDeviceToHost);
-    const char* names[] = {"v0 fract (current)", "v1 centred", "v2 centred+fold", "v3 fold+poly", "v4 libm sinf(30u)"};
+    const char* names[] = {"v0 fract", "v1 centred (two-float)", "v2 centred+fold", "v3 fold+poly", "v4 libm sinf(30u)", "v5 fma against n (4 ops)"};
     for (int v = 0; v < nv; ++v) {
         double mx = 0, ss = 0;
         for (int i = 0; i < n; ++i) {
