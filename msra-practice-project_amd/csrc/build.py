@@ -41,7 +41,7 @@ def build_profile(verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     out_dir = os.path.join(os.path.dirname(PKG), "gpurun_tools")
     os.makedirs(out_dir, exist_ok=True)
-    extra = os.environ.get("MI_EXTRA_DEFS", "").split()          # e.g. -DMI_DIAG_NOROWS=1 (tools/diag_build.sh)
+    extra = os.environ.get("MI_EXTRA_DEFS", "").split()          # extra -D switches for one-off diagnostic builds
     out = os.path.join(out_dir, os.environ.get("MI_PROF_NAME", "libmirender_prof.so"))
     srcs = [os.path.join(HERE, s) for s in SOURCES]
     cmd = [hipcc, *COMMON, "-DMI_PROFILE_STAMPS", *extra, "-shared", *srcs, "-o", out]

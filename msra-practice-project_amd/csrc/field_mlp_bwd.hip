@@ -135,16 +135,17 @@ enum BwdEpi : int { EPI_LINEAR = 0, EPI_RELU = 1, EPI_SIN = 2, EPI_FILM = 3 };
 
 // EPI_SIN / EPI_FILM: saved = the layer's X rows with the cosine's sign in the lowest mantissa bit; the derivative
 // factor C = 30 cos(30 u) is rebuilt from them (mi_math.h:dsin30_from_saved) one K block after the quarter's load
-// was issued, in the same mid slot that issues the load of the quarter eight further on.
+// was issued, in the mid slot that issues a later quarter's load.
 // EPI_FILM: writes dL/du = dX (.) C rows and leaves dA = gamma (.) dL/du in X; gamma is
 // this layer's FiLM row in LDS (`film_row`).  FILM layers also DMA the next epilogue's FiLM row (`next_film_layer`)
 // into the other film slot; `issue_slot` is the slot pair index handed to the stage issue (its aux / film
 // target is issue_slot ^ 1), `aux_slot` the slot the SCALED start row is read from.
 // Row traffic is spread over the layer instead of bursting in one row (32 x 1 KiB per wave inside 2048 cycles
-// saturates the CU's vector-memory path and stalls the in-order wave): the saved-row quarter for part j is loaded
-// in mid slot 2(j%8) of K block j/8, and with DEFER the dA rows this layer produces are not stored by its own
-// epilogue but by the NEXT layer's mid slots 2(j%8)+1 (they sit unchanged in X, that layer's B operand, until its
-// last row) - PREV_MB blocks to `prev_dA`.  FiLM layers cannot defer (they store dL/du but carry gamma dL/du).
+// saturates the CU's vector-memory path and stalls the in-order wave): the saved-row quarters are loaded one per mid
+// slot - 8-K-block layers: quarter j in slot 4(j%6) of K block j/6; 4-K-block layers: slot 2(j%8) of K block j/8 - and
+// with DEFER the dA rows this layer produces are not stored by its own epilogue but by the NEXT layer's mid slots
+// (slot 4(j%4)+2 of K block j/4, resp. 2(j%8)+1 of K block j/8; they sit unchanged in X, that layer's B operand, until
+// its last row) - PREV_MB blocks to `prev_dA`.  FiLM layers cannot defer (they store dL/du but carry gamma dL/du).
 template <int KB, int MB, int NEXT_AUX, int NEXT_BLOCK, int EPI, bool SCALED, bool FILM = false, bool DEFER = false,
           int PREV_MB = 0, class BSel>
 __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float s, BSel bsel, f32x16 (&acc)[8],
@@ -196,25 +197,13 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
 #pragma unroll
             for (int q = 0; q < 4; ++q) sv[j - 8][q] = dsin30_from_saved(sv[j - 8][q]);
         }
-        if constexpr (KB != 8 && kb < 4 && slot < 16) {
-#ifdef MI_DIAG_NOROWS      // diagnostic builds only (tools/diag_build.sh): 1 = no row loads, 2 = no deferred row stores, 3 = neither
-            if constexpr ((slot & 1) == 0) {
-                if constexpr (EPI != EPI_LINEAR && j < MB * 4) {
-                    if constexpr (MI_DIAG_NOROWS & 1) sv[j] = f32x4{1.f, 1.f, 1.f, 1.f};
-                    else sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
-                }
-            } else if constexpr (j < PREV_MB * 4 && !(MI_DIAG_NOROWS & 2)) {
-                constexpr int m = j / 4, rg = j % 4;
-                prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
-            }
-#else
+        if constexpr (KB != 8 && kb < 4 && slot < 16) {          // 4 K blocks: all 16 mid slots of rows 1-2 are needed
             if constexpr ((slot & 1) == 0) {
                 if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
             } else if constexpr (j < PREV_MB * 4) {
                 constexpr int m = j / 4, rg = j % 4;
                 prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
-#endif
         }
     };
     const auto post = [&](auto mc, auto pc) {
@@ -230,7 +219,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             if constexpr (EPI == EPI_FILM) X[m][4 * rg + q] = o[q] * g[q];
             else X[m][4 * rg + q] = o[q];
         }
-        if constexpr (!DEFER) drow[m * 8 + rg * 2] = o;       // (kept in MI_DIAG_NOROWS: keeps the chain live)
+        if constexpr (!DEFER) drow[m * 8 + rg * 2] = o;
     };
     mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !SCALED>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
                                                                        NoHook{}, bsel, acc, pre, post, mid);

@@ -6,14 +6,6 @@ set -e
 cd "$(dirname "$0")/.."
 C=msra-practice-project_amd/csrc
 mkdir -p gpurun_tools
-if [ "$1" = "norows" ]; then   # the backward chain without its row loads (1) / deferred stores (2) / both (3): wrong results, timing only
-  for v in 1 2 3; do
-    ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DMI_DIAG_NOROWS=$v -c $C/field_mlp_bwd.hip -o /tmp/field_mlp_bwd_norows$v.o &&
-      /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $C/_obj/field_mlp.o /tmp/field_mlp_bwd_norows$v.o $C/_obj/render_stages.o $C/_obj/eval_stages.o $C/_obj/adam_step.o $C/_obj/api.o -o gpurun_tools/libmirender_norows$v.so && echo "built norows $v" ) &
-  done
-  wait
-  exit 0
-fi
 for mode in "$@"; do
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DMI_DIAG_SIN=$mode -c $C/field_mlp.hip -o /tmp/field_mlp_diag$mode.o &&
     /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 /tmp/field_mlp_diag$mode.o $C/_obj/field_mlp_bwd.o $C/_obj/render_stages.o $C/_obj/eval_stages.o $C/_obj/adam_step.o $C/_obj/api.o -o gpurun_tools/libmirender_diag$mode.so &&
