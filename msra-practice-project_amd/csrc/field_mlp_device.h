@@ -353,7 +353,8 @@ struct SaveRows {
 // layer's inputs may be X itself (in place: block m of X is rewritten only after every K block that reads it has been
 // consumed).
 // Training stores do not burst either: with DEFER_X this layer's X rows are written by the NEXT layer's mid slots
-// (slot 2(j%8)+1 of K block j/8 for quarter j; X is that layer's B operand and unchanged until its last row) - that
+// (slot 4(j%4)+1 of K block j/4 for quarter j when that layer has 8 K blocks, else 2(j%PPC)+1 of K block j/PPC; X is
+// that layer's B operand and unchanged until its last row) - that
 // layer receives them as `prev` (PREV_MB blocks).  Sin layers save an ENCODING of X (cosine sign in the lowest bit)
 // that is not what the registers carry on, so their rows are stored by the activation hook itself, one quarter per
 // hook.
