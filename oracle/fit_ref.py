@@ -17,10 +17,11 @@ NEAR, FAR = 2.0, 6.0
 
 
 class Scene:
-    """`n_views` training views + one held-out view of a teacher tiny_nerf ("medium" density), res x res pixels."""
+    """`n_views` training views + one held-out view of a teacher tiny_nerf ("medium" density), res x res pixels;
+    the student pair is of kind `student` (tiny_nerf: PE + ReLU, or siren_nerf: the sin(30 u) family)."""
 
-    def __init__(self, res=24, n_views=6, nc=16, nf=16, seed=100):
-        self.res, self.nc, self.nf = res, nc, nf
+    def __init__(self, res=24, n_views=6, nc=16, nf=16, seed=100, student="tiny_nerf"):
+        self.res, self.nc, self.nf, self.student = res, nc, nf, student
         self.focal = 1.3875 * res
         sd_t = synth.state_dict("tiny_nerf", seed=seed, sharp="medium", bias_jitter=0.05)
         teacher = ofields.make_field("tiny_nerf", sd_t)
@@ -35,8 +36,8 @@ class Scene:
         self.images = imgs                                    # [res*res, 3] each; the last one is held out
         self.train_rays = torch.cat(self.rays[:-1])
         self.train_rgb = torch.cat(self.images[:-1])
-        self.student_init = (synth.state_dict("tiny_nerf", seed=seed + 1, bias_jitter=0.02),
-                             synth.state_dict("tiny_nerf", seed=seed + 2, bias_jitter=0.02))
+        self.student_init = (synth.state_dict(student, seed=seed + 1, bias_jitter=0.02),
+                             synth.state_dict(student, seed=seed + 2, bias_jitter=0.02))
 
     def batch(self, step: int, batch_size: int):
         """Deterministic batches: a fixed permutation of all training rays, walked in order (train_nerf.py:140-147)."""
@@ -55,17 +56,22 @@ def lr_at(step, lr0=5e-4, decay=250):
     return lr0 * (0.1 ** (step / (decay * 1000)))            # train_nerf.py:170-173
 
 
-def fit_cpu(scene: Scene, steps: int, batch_size: int):
-    """The reference loop on CPU autograd through the oracle.  Returns (losses[steps], heldout_psnr, state dicts)."""
-    sd_c = {k: v.clone().requires_grad_(True) for k, v in scene.student_init[0].items()}
-    sd_f = {k: v.clone().requires_grad_(True) for k, v in scene.student_init[1].items()}
-    fc, ff = ofields.make_field("tiny_nerf", sd_c), ofields.make_field("tiny_nerf", sd_f)
+def fit_cpu(scene: Scene, steps: int, batch_size: int, f64: bool = False):
+    """The reference loop on CPU autograd through the oracle.  Returns (losses[steps], heldout_psnr, state dicts).
+    f64: the same loop with weights, activations and optimiser state in double - how far apart two correct
+    implementations of this loop may drift (sin networks amplify rounding differences from the first Adam steps on)."""
+    cast = (lambda v: v.double()) if f64 else (lambda v: v)
+    sd_c = {k: cast(v).clone().requires_grad_(True) for k, v in scene.student_init[0].items()}
+    sd_f = {k: cast(v).clone().requires_grad_(True) for k, v in scene.student_init[1].items()}
+    fc, ff = ofields.make_field(scene.student, sd_c), ofields.make_field(scene.student, sd_f)
+    render = R.render_rays_f64 if f64 else R.render_rays
     params = list(sd_c.values()) + list(sd_f.values())
     opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))                # train_nerf.py:98
     losses = []
     for step in range(steps):
         rays, rgb, tr = scene.batch(step, batch_size)
-        out = R.render_rays(rays, NEAR, FAR, fc, ff, scene.nc, scene.nf, tr)
+        out = render(rays, NEAR, FAR, fc, ff, scene.nc, scene.nf, tr)
+        rgb = cast(rgb)
         loss = torch.mean((out.rgb_f - rgb) ** 2) + torch.mean((out.rgb_c - rgb) ** 2)      # :158-166
         opt.zero_grad()
         loss.backward()
@@ -74,6 +80,6 @@ def fit_cpu(scene: Scene, steps: int, batch_size: int):
             g["lr"] = lr_at(step + 1)
         losses.append(float(loss.detach()))
     with torch.no_grad():
-        held = R.render_rays(scene.rays[-1], NEAR, FAR, fc, ff, scene.nc, scene.nf, scene.heldout_jitter())
+        held = render(scene.rays[-1], NEAR, FAR, fc, ff, scene.nc, scene.nf, scene.heldout_jitter())
     psnr = R.psnr(held.rgb_f.numpy(), scene.images[-1].numpy())
     return losses, psnr, ({k: v.detach() for k, v in sd_c.items()}, {k: v.detach() for k, v in sd_f.items()})
