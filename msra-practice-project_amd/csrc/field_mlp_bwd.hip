@@ -154,6 +154,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
                                           int next_film_layer = 0, const float* film_row = nullptr,
                                           float* __restrict__ prev_dA = nullptr, int64_t prev_ld = 0) {
     static_assert(KB >= 4, "four K blocks are the fewest whose mid slots carry the 32 row quarters");
+    static_assert(KB != 8 || MB == 8, "the 8-K-block slot mapping below counts on 24 mid slots per K block (MB = 8)");
     static_assert(!(DEFER && EPI == EPI_FILM), "FiLM layers store dL/du, not what they carry on");
     const int h = c.h;
     const lds4_t pv = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
