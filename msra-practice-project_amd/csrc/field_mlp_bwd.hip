@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void film_finish_kernel(const float* __restric
 // dW GEMM over points: dW[f][k] = sum_p dA[p][f] X[p][k].  Features sit on the MFMA lanes: lane i of wave-tile
 // (wm, wk) owns dA features 128*wm + 4*i + c (c = the four 32-wide row blocks) and X features 32*CB*wk + CB*i + d,
 // acc[c][d] (+)= A_c (x) B_d per point pair.  Workgroup = 4 waves = tiles (WM x WK) x k-split KS = 4 / (WM*WK).
-// partial record (slab*KS + ks) = [TM][TK] row-major tile, then (with_bias) the TM column sums of dA.
+// partial record (slab) = [TM][TK] row-major tile, then (with_bias) the TM column sums of dA.
 // Rows are staged through LDS by DMA (buffer_load ... lds) rather than loaded per lane (the first version: 4 ms
 // of a 60 ms step slower):
 // a stage = 32 points = one contiguous run of rows of each operand ([point][feature] rows with lda == TM and
@@ -596,9 +596,20 @@ constexpr int kMaxGemmJobs = 12;
 struct GemmBatch {
     const float* dA[kMaxGemmJobs];
     const float* X[kMaxGemmJobs];
-    float* partial[kMaxGemmJobs];      // records (slab*KS + ks) of TM*TK (+ TM bias sums) floats
+    float* partial[kMaxGemmJobs];      // one record per slab of TM*TK (+ TM bias sums) floats
     int with_bias[kMaxGemmJobs];
 };
+
+// LDS floats one k-split wave parks for the merge (its 4 x CB accumulator blocks + the bias sums), and the dynamic LDS a
+// launch needs: the two stage buffers, or the merge area of the (KS - 1) x TILES parked waves if that is larger.
+constexpr int gemm_merge_wave_floats(int CB) { return (4 * CB * 16 + 4) * 64; }
+template <int CB, int WM, int WK>
+constexpr size_t gemm_lds_bytes() {
+    constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
+    constexpr size_t stage = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
+    constexpr size_t merge = (size_t)(KS - 1) * TILES * gemm_merge_wave_floats(CB) * sizeof(float);
+    return stage > merge ? stage : merge;
+}
 
 template <int CB, int WM, int WK>
 __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t P, int slab_pts) {
@@ -672,8 +683,40 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
             });
         });
     }
+    // The k-split waves of a workgroup (KS = 2 or 4 for the narrow tiles) hold partial sums of the SAME tile: they are
+    // added here, through the stage buffers, in k order - one record per slab instead of KS (the narrow GEMMs of a
+    // NeRF step wrote and re-read 2-4x the partial bytes of the wide ones for a fraction of their work).
+    if constexpr (KS > 1) {
+        constexpr int WF = gemm_merge_wave_floats(CB);
+        __syncthreads();                                             // every wave has left the stage buffers
+        if (ks > 0) {
+            float* mine = smem + ((ks - 1) * TILES + tile) * WF + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < CB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[((c * CB + d) * 16 + r) * 64] = acc[c][d][r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) mine[(4 * CB * 16 + q) * 64] = bsum[q];
+        }
+        __syncthreads();
+        if (ks > 0) return;
+#pragma unroll
+        for (int k = 1; k < KS; ++k) {
+            const float* o = smem + ((k - 1) * TILES + tile) * WF + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < CB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[c][d][r] += o[((c * CB + d) * 16 + r) * 64];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bsum[q] += o[(4 * CB * 16 + q) * 64];
+        }
+    }
     // write the partial tile: D[row i'][col j] on lane (j, h), reg r: i' = (r&3) + 8*(r>>2) + 4*h
-    float* out = partial + ((int64_t)blockIdx.x * KS + ks) * (TM * TK + (with_bias ? TM : 0));
+    float* out = partial + (int64_t)blockIdx.x * (TM * TK + (with_bias ? TM : 0));
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -946,14 +989,14 @@ struct GemmJob {
 template <int CB, int WM, int WK>
 static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P, float* partial, float* gw, int w_ld,
                     int w_col0, int rows_valid, int cols_valid, float* gb, hipStream_t stream) {
-    constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
+    constexpr int TM = 128 * WM, TK = 32 * CB * WK;
     const int slab = slab_points(P);
     const int slabs = (int)((P + slab - 1) / slab);
-    const int n = slabs * KS;
+    const int n = slabs;                                                              // the k-split waves merge in the kernel
     const int rec = TM * TK + (gb ? TM : 0);                                          // tile (+ bias sums) per record
     float* tmp = partial + (int64_t)n * rec;                                          // level-1 sums
     if (lda != TM || ldx != TK) { set_error("dw_gemm: rows must be dense (lda %d != %d or ldx %d != %d)", lda, TM, ldx, TK); return -1; }
-    constexpr size_t lds = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
+    constexpr size_t lds = gemm_lds_bytes<CB, WM, WK>();
     static PerDeviceOnce attr_once;                                                   // one per template instance
     const int arc = attr_once.run([&]() {
         if (hipFuncSetAttribute((const void*)dw_gemm_kernel<CB, WM, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1099,17 +1142,16 @@ struct BwdBatcher {
     template <int CB, int WM, int WK>
     int flush(Group& g) {
         if (!g.n) return 0;
-        constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
         const int slabs = slabs_for(P, g.n), slab = slab_pts_for(P, slabs);
         const int n_slabs = (int)((P + slab - 1) / slab);
         for (int i = 0; i < g.n; ++i) {
-            g.red[i].n = n_slabs * KS;
+            g.red[i].n = n_slabs;                             // one record per slab (k-split waves merge in the kernel)
             g.b.partial[i] = take((int64_t)g.red[i].n * g.red[i].rec);
             g.red[i].src = g.b.partial[i];
             add_reduce(g.red[i]);
         }
         if (!partial) return 0;
-        constexpr size_t lds = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
+        constexpr size_t lds = gemm_lds_bytes<CB, WM, WK>();
         static PerDeviceOnce attr_once;                                               // one per template instance
         const int arc = attr_once.run([&]() {
             if (hipFuncSetAttribute((const void*)dw_gemm_kernel<CB, WM, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
