@@ -89,7 +89,7 @@ class _NerfLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g_out):
-        g = [t * g_loss for t in ctx.saved_tensors]
+        g = torch._foreach_mul(list(ctx.saved_tensors), g_loss)          # one launch for the four seeds
         return g[0], g[1], g[2], g[3], None, None, None
 
 
