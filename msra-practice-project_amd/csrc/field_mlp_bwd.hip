@@ -734,59 +734,6 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
     }
 }
 
-// Cross-slab reduction, deterministic (fixed order), two levels so it streams at HBM rate:
-// level 1 sums groups of kReduceGroup partial tiles into tmp (grid.y = groups, float4 per thread, 4 loads in
-// flight); level 2 sums the groups into the gradient tensor with its row/column validity and placement.
-constexpr int kReduceGroup = 16;
-
-__global__ __launch_bounds__(256) void reduce_level1_kernel(const float* __restrict__ partial, int n_partials,
-                                                            int tile_floats, float* __restrict__ tmp) {
-    const int idx4 = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx4 * 4 >= tile_floats) return;
-    const int k0 = blockIdx.y * kReduceGroup;
-    const int k1 = k0 + kReduceGroup < n_partials ? k0 + kReduceGroup : n_partials;
-    const f32x4* src = reinterpret_cast<const f32x4*>(partial) + idx4;
-    const int64_t stride4 = tile_floats / 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int k = k0;
-    for (; k + 4 <= k1; k += 4) {
-        const f32x4 a = src[(int64_t)k * stride4], b = src[(int64_t)(k + 1) * stride4];
-        const f32x4 c = src[(int64_t)(k + 2) * stride4], d = src[(int64_t)(k + 3) * stride4];
-        s += a; s += b; s += c; s += d;
-    }
-    for (; k < k1; ++k) s += src[(int64_t)k * stride4];
-    reinterpret_cast<f32x4*>(tmp)[(int64_t)blockIdx.y * stride4 + idx4] = s;
-}
-
-// The same over records of rec_floats = TM*TK (+ TM bias sums): element idx < TM*TK goes to the weight gradient,
-// the tail (when bias_dst) to the bias gradient - one launch for both.
-__global__ void reduce_records_kernel(const float* __restrict__ partial, int n_partials, int rec_floats, int TM, int TK,
-                                      float* __restrict__ dst, int dst_ld, int dst_col0, int rows_valid, int cols_valid,
-                                      float* __restrict__ bias_dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rec_floats) return;
-    const bool is_bias = idx >= TM * TK;
-    const int row = is_bias ? idx - TM * TK : idx / TK, col = is_bias ? 0 : idx % TK;
-    if (row >= rows_valid || (!is_bias && col >= cols_valid) || (is_bias && !bias_dst)) return;
-    float s = 0.f;
-    for (int k = 0; k < n_partials; ++k) s += partial[(int64_t)k * rec_floats + idx];
-    if (is_bias) bias_dst[row] = s;
-    else dst[(int64_t)row * dst_ld + dst_col0 + col] = s;
-}
-
-// dst[row][dst_col0 + col] = sum over partials (fixed order), rows < rows_valid, cols < cols_valid
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int n_partials, int TM, int TK,
-                                       float* __restrict__ dst, int dst_ld, int dst_col0, int rows_valid,
-                                       int cols_valid) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= TM * TK) return;
-    const int row = idx / TK, col = idx % TK;
-    if (row >= rows_valid || col >= cols_valid) return;
-    float s = 0.f;
-    for (int k = 0; k < n_partials; ++k) s += partial[(int64_t)k * TM * TK + idx];
-    dst[(int64_t)row * dst_ld + dst_col0 + col] = s;
-}
-
 // Thin gradients: out[c][f] = sum_p S[p][c0+c] * H[p][f] for c < nc <= 3, f < F <= 256, plus sum_p S[p][c0+c].
 //   heads:        S = head pre-activation grads [P,4], H = the head's input  -> dW_head[c][f], db_head[c]
 //   K = 3 inputs: S = xin [P,8] (xyz | dir),           H = dA of the layer   -> dW[f][col0 + c]
@@ -845,18 +792,6 @@ __global__ __launch_bounds__(256) void thin_grad_kernel(ThinBatch tb, int64_t P,
     if (f < 4) {
         float* bo = bias_partial + (int64_t)blockIdx.x * 4;
         bo[f] = f < 3 ? ((red[0][3][f] + red[1][3][f]) + red[2][3][f]) + red[3][3][f] : 0.f;
-    }
-}
-
-// dst[f*ld + col0 + c] = sum_k partial[k][c][f]   (K = 3 weight columns)
-__global__ void reduce_columns_kernel(const float* __restrict__ partial, int n, int nc, int F, float* __restrict__ dst,
-                                      int ld, int col0) {
-    const int f = threadIdx.x;
-    if (f >= F) return;
-    for (int c = 0; c < nc; ++c) {
-        float s = 0.f;
-        for (int k = 0; k < n; ++k) s += partial[((int64_t)k * 4 + c) * 256 + f];
-        dst[(int64_t)f * ld + col0 + c] = s;
     }
 }
 
@@ -939,100 +874,23 @@ int64_t train_grads_floats(int kind) {
     }
     return -1;
 }
-// FiLM scratch: one image's T (256x256), its raw-input columns (256x3, padded) and column sums s (256)
+// FiLM scratch: one image's T_l (256x256) and column sums s_l (256) per 256-wide layer, its raw-input columns (256x3, padded)
+constexpr int64_t kFilmLayerScratch = 256 * 256 + 256;       // T_l and s_l of one 256-wide FiLM layer
 int64_t film_partial_floats(int64_t /*n_groups*/, int64_t /*points_per_group*/) {
-    return 256 * 256 + 256 * 4 + 256;
+    return 8 * kFilmLayerScratch + 2 * 256 * 4 + 256;        // eight layers, two K = 3 blocks, s_0 (launch_field_backward)
 }
 
-static int slab_points(int64_t P) {
-    int64_t s = (P + 255) / 256;           // aim at one workgroup per CU: fewer partial tiles to write and reduce
-    s = (s + 31) / 32 * 32;
-    if (s < 256) s = 256;
-    return (int)s;
-}
 static int64_t batched_partial_floats(int kind, int64_t P);
 int64_t bwd_partial_floats(int64_t P) {
-    const int slab = slab_points(P);
-    const int64_t slabs = (P + slab - 1) / slab;
-    const int64_t tiles = slabs * 4;                                   // up to 4 k-split partial tiles per slab
-    const int64_t groups = (tiles + kReduceGroup - 1) / kReduceGroup;
-    int64_t most = (tiles + groups) * (256 * 256 + 256) + 1024;        // FiLM kinds: one GEMM at a time (records + level-1 sums)
+    // FiLM kinds: one image at a time - eight GEMM jobs of at most 32 slabs each, two thin jobs, a column sum (or the
+    // two head jobs over all images): an upper bound whatever the image size.  launch_field_backward checks every
+    // pass's real plan against this figure before it launches anything.
+    int64_t most = (int64_t)8 * 32 * kFilmLayerScratch + 2 * 128 * 1280 + 256 * 256 + 4096;
     for (int kind : {0, 1, 4}) {                                       // the others: every job of the pass at once
         const int64_t n = batched_partial_floats(kind, P);
         if (n > most) most = n;
     }
     return most;
-}
-
-// Sum `n` partial tiles of TM x TK (at `partial`, level-1 scratch at `tmp`) into dst.
-static void reduce_tiles(const float* partial, int n, int TM, int TK, float* tmp, float* dst, int dst_ld, int dst_col0,
-                         int rows_valid, int cols_valid, hipStream_t stream) {
-    const int tile = TM * TK;
-    if (n > kReduceGroup && tile % 4 == 0) {
-        const int groups = (n + kReduceGroup - 1) / kReduceGroup;
-        hipLaunchKernelGGL(reduce_level1_kernel, dim3((tile / 4 + 255) / 256, groups), dim3(256), 0, stream, partial, n,
-                           tile, tmp);
-        partial = tmp;
-        n = groups;
-    }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((tile + 255) / 256), dim3(256), 0, stream, partial, n, TM, TK, dst,
-                       dst_ld, dst_col0, rows_valid, cols_valid);
-}
-
-struct GemmJob {
-    int a_region, M;          // dA region, rows (256 or 128)
-    int x_region, x_col_valid, K;   // X region, valid columns, padded K (256, 64 or 32)
-    int w_param, w_ld, w_col0;      // destination weight grad [M, w_ld] at column w_col0
-    int b_param;                    // bias grad (or -1 when another job of the same layer writes it)
-};
-
-template <int CB, int WM, int WK>
-static int run_gemm(const float* dA, int lda, const float* X, int ldx, int64_t P, float* partial, float* gw, int w_ld,
-                    int w_col0, int rows_valid, int cols_valid, float* gb, hipStream_t stream) {
-    constexpr int TM = 128 * WM, TK = 32 * CB * WK;
-    const int slab = slab_points(P);
-    const int slabs = (int)((P + slab - 1) / slab);
-    const int n = slabs;                                                              // the k-split waves merge in the kernel
-    const int rec = TM * TK + (gb ? TM : 0);                                          // tile (+ bias sums) per record
-    float* tmp = partial + (int64_t)n * rec;                                          // level-1 sums
-    if (lda != TM || ldx != TK) { set_error("dw_gemm: rows must be dense (lda %d != %d or ldx %d != %d)", lda, TM, ldx, TK); return -1; }
-    constexpr size_t lds = gemm_lds_bytes<CB, WM, WK>();
-    static PerDeviceOnce attr_once;                                                   // one per template instance
-    const int arc = attr_once.run([&]() {
-        if (hipFuncSetAttribute((const void*)dw_gemm_kernel<CB, WM, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) { set_error("hipFuncSetAttribute(dw_gemm) failed"); return -2; }
-        return 0;
-    });
-    if (arc) return arc;
-    GemmBatch one{};
-    one.dA[0] = dA; one.X[0] = X; one.partial[0] = partial; one.with_bias[0] = gb ? 1 : 0;
-    hipLaunchKernelGGL((dw_gemm_kernel<CB, WM, WK>), dim3(slabs), dim3(256), lds, stream, one, P, slab);
-    const float* src = partial;
-    int m = n;
-    if (m > kReduceGroup) {
-        const int groups = (m + kReduceGroup - 1) / kReduceGroup;
-        hipLaunchKernelGGL(reduce_level1_kernel, dim3((rec / 4 + 255) / 256, groups), dim3(256), 0, stream, src, m, rec, tmp);
-        src = tmp;
-        m = groups;
-    }
-    hipLaunchKernelGGL(reduce_records_kernel, dim3((rec + 255) / 256), dim3(256), 0, stream, src, m, rec, TM, TK, gw, w_ld,
-                       w_col0, rows_valid, cols_valid, gb);
-    return check_launch("dw_gemm");
-}
-
-static int run_head(const float* dpre, int c0, int nc, const float* H, int ldh, int F, int64_t P, float* partial,
-                    float* gw, float* gb, hipStream_t stream) {
-    const int slab = slab_points(P);
-    const int slabs = (int)((P + slab - 1) / slab);
-    float* tmp = partial + (int64_t)slabs * 4 * 256;
-    float* bias_partial = tmp + (int64_t)((slabs + kReduceGroup - 1) / kReduceGroup) * 4 * 256;
-    ThinBatch one{};
-    one.S[0] = dpre; one.lds_[0] = 4; one.c0[0] = c0; one.nc[0] = nc; one.H[0] = H; one.ldh[0] = ldh; one.F[0] = F;
-    one.partial[0] = partial; one.bias_partial[0] = bias_partial;
-    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, one, P, slab);
-    reduce_tiles(partial, slabs, 4, 256, tmp, gw, F, 0, nc, F, stream);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, bias_partial, slabs, 1, 4, gb, 4, 0, 1, nc);
-    return check_launch("head_grad");
 }
 
 // bias gradient of a layer with no GEMM job (K = 3 inputs): column sums of dA over the points
@@ -1058,37 +916,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     __syncthreads();
     const int f = threadIdx.x;
     partial[(int64_t)blockIdx.x * 256 + f] = ((red[0][f] + red[1][f]) + red[2][f]) + red[3][f];
-}
-
-static int run_colsum(const float* dA, int lda, int F, int64_t P, float* partial, float* gb, hipStream_t stream) {
-    const int slab = slab_points(P);
-    const int slabs = (int)((P + slab - 1) / slab);
-    float* tmp = partial + (int64_t)slabs * 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(slabs), dim3(256), 0, stream, dA, lda, F, P, slab, partial);
-    reduce_tiles(partial, slabs, 1, 256, tmp, gb, 256, 0, 1, F, stream);
-    return check_launch("colsum");
-}
-
-// dW[:, col0:col0+3] of a layer whose inputs include the raw xyz (c0 = 0) or view direction (c0 = 3)
-static int run_k3(const float* xin, int c0, const float* dA, int lda, int F, int64_t P, float* partial, float* gw,
-                  int w_ld, int w_col0, hipStream_t stream) {
-    const int slab = slab_points(P);
-    const int slabs = (int)((P + slab - 1) / slab);
-    float* tmp = partial + (int64_t)slabs * 4 * 256;
-    float* bias_partial = tmp + (int64_t)((slabs + kReduceGroup - 1) / kReduceGroup) * 4 * 256;
-    ThinBatch one{};
-    one.S[0] = xin; one.lds_[0] = 8; one.c0[0] = c0; one.nc[0] = 3; one.H[0] = dA; one.ldh[0] = lda; one.F[0] = F;
-    one.partial[0] = partial; one.bias_partial[0] = bias_partial;
-    hipLaunchKernelGGL(thin_grad_kernel, dim3(slabs), dim3(256), 0, stream, one, P, slab);
-    const float* src = partial;
-    int n = slabs;
-    if (n > kReduceGroup) {
-        const int groups = (n + kReduceGroup - 1) / kReduceGroup;
-        hipLaunchKernelGGL(reduce_level1_kernel, dim3(1, groups), dim3(256), 0, stream, partial, n, 1024, tmp);
-        src = tmp; n = groups;
-    }
-    hipLaunchKernelGGL(reduce_columns_kernel, dim3(1), dim3(256), 0, stream, src, n, 3, F, gw, w_ld, w_col0);
-    return check_launch("k3_grad");
 }
 
 // ---- batched orchestration (NeRF, TinyNeRF, SirenNeRF) -----------------------------------------------------------
@@ -1314,11 +1141,18 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
         if ((rc = check_launch("film_bwd_kernel"))) return rc;
         constexpr RegionLayout AL = film_acts();
         const int64_t ppg = points_per_group;
-        float* T = film_partial;                 // [256][256] of the current image
-        float* T3 = T + 256 * 256;               // [256][3]
-        float* sg = T3 + 256 * 4;                // [256]
+        // FiLM scratch of the current image: T_l [256][256] + s_l [256] for the eight 256-wide FiLM layers, the K = 3
+        // blocks of layer 0 (xyz) and of layer 8 (dir) as [256][3] (padded to 4), s_0 [256]
+        const auto Tl = [&](int l) { return film_partial + (int64_t)(l - 1) * kFilmLayerScratch; };
+        const auto sl = [&](int l) { return Tl(l) + 256 * 256; };
+        float* T3_0 = film_partial + 8 * kFilmLayerScratch;
+        float* T3_8 = T3_0 + 256 * 4;
+        float* s0 = T3_8 + 256 * 4;
         const int ld9 = use_dir ? 259 : 256;
-        // Per image g (fixed order, so the sums over images are deterministic): T_g, s_g of every FiLM layer, then
+        // Per image g (fixed order, so the sums over images are deterministic): T_g, s_g of every FiLM layer - the eight
+        // 256 x 256 GEMMs of an image are ONE launch (grid.y = layer, a job needs only 32 slabs to give every CU a
+        // workgroup, so 8x fewer partial tiles are written and re-read than with a launch per layer), the K = 3 blocks
+        // one thin launch, one reduction launch for all of them - then per layer
         // dW += gamma_g (.) T_g, db += gamma_g (.) s_g, d gamma_g = <W, T_g> + b (.) s_g, d beta_g = s_g.
         for (int64_t g = 0; g < n_groups; ++g) {
             const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P + g * ppg * AL.width[r]; };
@@ -1326,34 +1160,50 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
             const float* frow = film + (g * kFilmLayers) * kFilmRow;
             float* dfrow = grad_film + (g * kFilmLayers) * kFilmRow;
             const int first = g == 0;
-            const auto finish = [&](const float* t, int tk, int l, int wp, int w_ld, int col0, int bias_part) {
+            const auto jobs = [&](BwdBatcher& bb) -> int {
+                for (int l = 1; l <= 8; ++l)                                  // FiLM layer l: input X_{l-1} = acts region l
+                    bb.gemm<4, 2, 2>(bb.g422, G(l), A(l), Tl(l), 256, 0, 256, 256, sl(l));
+                bb.thin_job(A(0), 8, 0, 3, G(0), 256, 256, T3_0, 3, 0, true, nullptr);              // input_layer (K = 3: xyz)
+                if (use_dir) bb.thin_job(A(0), 8, 3, 3, G(8), 256, 256, T3_8, 3, 0, true, nullptr); // hidden_layer_rgb's dir columns
+                int r;
+                if ((r = bb.colsum(G(0), 256, 256, s0))) return r;
+                if ((r = bb.flush<4, 2, 2>(bb.g422))) return r;
+                if ((r = bb.flush_thin())) return r;
+                return bb.reduce_all();
+            };
+            if (first) {                             // dry run: this image's scratch plan against what the caller was told to allocate
+                BwdBatcher plan{ppg, nullptr, 0, stream};
+                (void)jobs(plan);
+                if (plan.used > bwd_partial_floats(P)) {
+                    set_error("FiLM backward scratch plan (%lld floats) exceeds mi_field_bwd_partial_floats (%lld)",
+                              (long long)plan.used, (long long)bwd_partial_floats(P));
+                    return -1;
+                }
+            }
+            BwdBatcher bb{ppg, partial, 0, stream};
+            if ((rc = jobs(bb))) return rc;
+            const auto finish = [&](const float* t, int tk, const float* sg, int l, int wp, int w_ld, int col0, int bias_part) {
                 hipLaunchKernelGGL(film_finish_kernel, dim3(256), dim3(256), 0, stream, t, tk, sg, params[2 * wp], w_ld, col0,
                                    params[2 * wp + 1], frow + l * kFilmRow, first, bias_part, gp[2 * wp], gp[2 * wp + 1],
                                    dfrow + l * kFilmRow);
             };
-            // input_layer (K = 3): FiLM layer 0, parameter pair 0
-            if ((rc = run_k3(A(0), 0, G(0), 256, 256, ppg, partial, T3, 3, 0, stream))) return rc;
-            if ((rc = run_colsum(G(0), 256, 256, ppg, partial, sg, stream))) return rc;
-            finish(T3, 3, 0, 0, 3, 0, 1);
-            // hidden_layers[l-1] (FiLM layer l, parameter pair l): input X_{l-1} = acts region l
-            for (int l = 1; l <= 7; ++l) {
-                if ((rc = run_gemm<4, 2, 2>(G(l), 256, A(l), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
-                finish(T, 256, l, l, 256, 0, 1);
-            }
-            // hidden_layer_rgb (FiLM layer 8, parameter pair 9): [X_7 | dir]
-            if ((rc = run_gemm<4, 2, 2>(G(8), 256, A(8), 256, ppg, partial, T, 256, 0, 256, 256, sg, stream))) return rc;
-            finish(T, 256, 8, 9, ld9, 0, 1);
-            if (use_dir) {
-                if ((rc = run_k3(A(0), 3, G(8), 256, 256, ppg, partial, T3, 3, 0, stream))) return rc;
-                finish(T3, 3, 8, 9, 259, 256, 0);
-            }
+            finish(T3_0, 3, s0, 0, 0, 3, 0, 1);                               // input_layer: FiLM layer 0, parameter pair 0
+            for (int l = 1; l <= 7; ++l) finish(Tl(l), 256, sl(l), l, l, 256, 0, 1);      // hidden_layers[l-1]: pair l
+            finish(Tl(8), 256, sl(8), 8, 9, ld9, 0, 1);                       // hidden_layer_rgb: FiLM layer 8, pair 9: [X_7 | dir]
+            if (use_dir) finish(T3_8, 3, sl(8), 8, 9, 259, 256, 0);
         }
         if ((rc = check_launch("film_finish_kernel"))) return rc;
         // heads: sigma (param pair 8) on X_7, rgb (pair 10) on X_8 - no FiLM in between, all images at once
         const auto A = [&](int r) { return acts + (int64_t)region_offset(AL, r) * P; };
         const float* dpre = grads + (int64_t)(9 * 256) * P;
-        if ((rc = run_head(dpre, 3, 1, A(8), 256, 256, P, partial, gp[16], gp[17], stream))) return rc;      // sigma x X_7
-        if ((rc = run_head(dpre, 0, 3, A(9), 256, 256, P, partial, gp[20], gp[21], stream))) return rc;      // rgb x X_8
+        for (int pass = 0; pass < 2; ++pass) {                        // 0: plan only (scratch check), 1: launch
+            BwdBatcher hb{P, pass ? partial : nullptr, 0, stream};
+            hb.thin_job(dpre, 4, 3, 1, A(8), 256, 256, gp[16], 256, 0, false, gp[17]);                        // sigma x X_7
+            hb.thin_job(dpre, 4, 0, 3, A(9), 256, 256, gp[20], 256, 0, false, gp[21]);                        // rgb x X_8
+            if ((rc = hb.flush_thin())) return rc;
+            if (!pass && hb.used > bwd_partial_floats(P)) { set_error("FiLM head scratch plan exceeds mi_field_bwd_partial_floats"); return -1; }
+            if ((rc = hb.reduce_all())) return rc;
+        }
     }
     return 0;
 }
