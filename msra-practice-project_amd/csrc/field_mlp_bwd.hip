@@ -734,7 +734,9 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
     }
 }
 
-// Thin gradients: out[c][f] = sum_p S[p][c0+c] * H[p][f] for c < nc <= 3, f < F <= 256, plus sum_p S[p][c0+c].
+// Thin gradients: out[c][f] = sum_p S[p][c0+c] * H[p][f] for c < nc <= 3, f < F <= 256, plus sum_p S[p][c0+c], plus - in
+// the record's fourth row, free once the rows are being read - the column sums sum_p H[p][f] (the bias gradient of a
+// layer whose weights are all K = 3 columns).
 //   heads:        S = head pre-activation grads [P,4], H = the head's input  -> dW_head[c][f], db_head[c]
 //   K = 3 inputs: S = xin [P,8] (xyz | dir),           H = dA of the layer   -> dW[f][col0 + c]
 // grid = (point slabs, jobs), block = 256 threads = features; partial[slab][4][256], bias_partial[slab][4] per job.
@@ -754,11 +756,12 @@ __global__ __launch_bounds__(256) void thin_grad_kernel(ThinBatch tb, int64_t P,
     // wave w takes points p0 + w, p0 + w + 4, ...; lane l the features 4l..4l+3 (float4 rows, 4 points in flight);
     // the four waves' sums are added in wave order at the end, so the result does not depend on timing
     __shared__ float red[4][4][256];
+    __shared__ float bred[4][4];
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
     const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
     const bool live = 4 * lane < F;
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
     const auto row = [&](int64_t p) {
         return live ? *reinterpret_cast<const f32x4*>(H + p * ldh + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -770,6 +773,7 @@ __global__ __launch_bounds__(256) void thin_grad_kernel(ThinBatch tb, int64_t P,
         for (int q = 0; q < 4; ++q) {
             a0[q] = fmaf(s0, hv[q], a0[q]); a1[q] = fmaf(s1, hv[q], a1[q]); a2[q] = fmaf(s2, hv[q], a2[q]);
         }
+        a3 += hv;
         b0 += s0; b1 += s1; b2 += s2;
     };
     int64_t p = p0 + w;
@@ -781,17 +785,17 @@ __global__ __launch_bounds__(256) void thin_grad_kernel(ThinBatch tb, int64_t P,
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         red[w][0][4 * lane + q] = a0[q]; red[w][1][4 * lane + q] = a1[q]; red[w][2][4 * lane + q] = a2[q];
+        red[w][3][4 * lane + q] = a3[q];
     }
-    if (lane == 0) { red[w][3][0] = b0; red[w][3][1] = b1; red[w][3][2] = b2; }
+    if (lane == 0) { bred[w][0] = b0; bred[w][1] = b1; bred[w][2] = b2; }
     __syncthreads();
     const int f = threadIdx.x;
     float* out = partial + (int64_t)blockIdx.x * 4 * 256;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c * 256 + f] = ((red[0][c][f] + red[1][c][f]) + red[2][c][f]) + red[3][c][f];
-    out[3 * 256 + f] = 0.f;
+    for (int c = 0; c < 4; ++c) out[c * 256 + f] = ((red[0][c][f] + red[1][c][f]) + red[2][c][f]) + red[3][c][f];
     if (f < 4) {
         float* bo = bias_partial + (int64_t)blockIdx.x * 4;
-        bo[f] = f < 3 ? ((red[0][3][f] + red[1][3][f]) + red[2][3][f]) + red[3][3][f] : 0.f;
+        bo[f] = f < 3 ? ((bred[0][f] + bred[1][f]) + bred[2][f]) + bred[3][f] : 0.f;
     }
 }
 
@@ -805,6 +809,7 @@ struct ReduceJob {
     float* dst;
     float* bias_dst;
     int n, rec, TM, TK, ld, col0, rows_valid, cols_valid, transposed;
+    int row0 = 0;               // first record row the job places (rows below it belong to another job over the same records)
 };
 struct ReduceBatch { ReduceJob job[kMaxReduceJobs]; };
 
@@ -840,10 +845,10 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceBatch rb) {
         const int e = idx + q;
         const bool is_bias = e >= j.TM * j.TK;
         const int row = is_bias ? e - j.TM * j.TK : e / j.TK, col = is_bias ? 0 : e % j.TK;
-        if (row >= j.rows_valid || (!is_bias && col >= j.cols_valid) || (is_bias && !j.bias_dst)) continue;
+        if (row >= j.rows_valid || (!is_bias && (col >= j.cols_valid || row < j.row0)) || (is_bias && !j.bias_dst)) continue;
         if (is_bias) j.bias_dst[row] = s[q];
         else if (j.transposed) j.dst[(int64_t)col * j.ld + j.col0 + row] = s[q];
-        else j.dst[(int64_t)row * j.ld + j.col0 + col] = s[q];
+        else j.dst[(int64_t)(row - j.row0) * j.ld + j.col0 + col] = s[q];
     }
 }
 
@@ -893,30 +898,6 @@ int64_t bwd_partial_floats(int64_t P) {
     return most;
 }
 
-// bias gradient of a layer with no GEMM job (K = 3 inputs): column sums of dA over the points
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dA, int lda, int F, int64_t P,
-                                                     int slab_pts, float* __restrict__ partial) {
-    __shared__ float red[4][256];
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t p0 = (int64_t)blockIdx.x * slab_pts;
-    const int64_t p1 = p0 + slab_pts < P ? p0 + slab_pts : P;
-    const bool live = 4 * lane < F;
-    const auto row = [&](int64_t p) {
-        return live ? *reinterpret_cast<const f32x4*>(dA + p * lda + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int64_t p = p0 + w;
-    for (; p + 12 < p1; p += 16) {
-        const f32x4 h0 = row(p), h1 = row(p + 4), h2 = row(p + 8), h3 = row(p + 12);
-        s = ((s + h0) + h1) + h2 + h3;
-    }
-    for (; p < p1; p += 4) s = s + row(p);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) red[w][4 * lane + q] = s[q];
-    __syncthreads();
-    const int f = threadIdx.x;
-    partial[(int64_t)blockIdx.x * 256 + f] = ((red[0][f] + red[1][f]) + red[2][f]) + red[3][f];
-}
 
 // ---- batched orchestration (NeRF, TinyNeRF, SirenNeRF) -----------------------------------------------------------
 // A backward pass is: the chain kernel, then every weight-gradient GEMM of one tile shape in ONE launch (grid.y =
@@ -932,8 +913,7 @@ struct BwdBatcher {
     struct Group { GemmBatch b{}; int n = 0; ReduceJob red[kMaxGemmJobs]; } g422, g221, g412, g111;
     ThinBatch thin{};
     int n_thin = 0;
-    ReduceJob thin_red[2 * kMaxThinJobs];
-    int n_thin_red = 0;
+    ReduceJob thin_red[3 * kMaxThinJobs];
     ReduceBatch all{};
     int n_red = 0, max_rec = 0;
 
@@ -991,15 +971,18 @@ struct BwdBatcher {
     }
     // out[c][f] = sum_p S[p][c0+c] H[p][f]: heads (dst [nc][F], bias gb[nc]) or K = 3 weight columns (transposed into
     // dst[f*ld + col0 + c], no bias)
+    // colsum_dst: also dst[f] = sum_p H[p][f] (the record's fourth row)
     void thin_job(const float* S, int lds_, int c0, int nc, const float* H, int ldh, int F, float* dst, int ld, int col0,
-                  bool transposed, float* gb) {
+                  bool transposed, float* gb, float* colsum_dst = nullptr) {
         const int i = n_thin++;
         thin.S[i] = S; thin.lds_[i] = lds_; thin.c0[i] = c0; thin.nc[i] = nc; thin.H[i] = H; thin.ldh[i] = ldh; thin.F[i] = F;
         // record [4][256]: row c, col f
-        thin_red[n_thin_red++] = transposed ? ReduceJob{nullptr, dst, nullptr, 0, 1024, 4, 256, ld, col0, nc, F, 1}
-                                            : ReduceJob{nullptr, dst, nullptr, 0, 1024, 4, 256, F, 0, nc, F, 0};
-        if (gb) thin_red[n_thin_red++] = ReduceJob{nullptr, gb, nullptr, 0, 4, 1, 4, 4, 0, 1, nc, 0};
-        else thin_red[n_thin_red++] = ReduceJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        thin_red[3 * i] = transposed ? ReduceJob{nullptr, dst, nullptr, 0, 1024, 4, 256, ld, col0, nc, F, 1}
+                                     : ReduceJob{nullptr, dst, nullptr, 0, 1024, 4, 256, F, 0, nc, F, 0};
+        thin_red[3 * i + 1] = gb ? ReduceJob{nullptr, gb, nullptr, 0, 4, 1, 4, 4, 0, 1, nc, 0}
+                                 : ReduceJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        thin_red[3 * i + 2] = colsum_dst ? ReduceJob{nullptr, colsum_dst, nullptr, 0, 1024, 4, 256, 256, 0, 4, F, 0, 3}
+                                         : ReduceJob{nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     }
     int flush_thin() {
         if (!n_thin) return 0;
@@ -1008,24 +991,15 @@ struct BwdBatcher {
         for (int i = 0; i < n_thin; ++i) {
             thin.partial[i] = take((int64_t)n_slabs * 1024);
             thin.bias_partial[i] = take((int64_t)n_slabs * 4);
-            ReduceJob a = thin_red[2 * i], b = thin_red[2 * i + 1];
+            ReduceJob a = thin_red[3 * i], b = thin_red[3 * i + 1], c = thin_red[3 * i + 2];
             a.n = n_slabs; a.src = thin.partial[i];
             add_reduce(a);
             if (b.dst) { b.n = n_slabs; b.src = thin.bias_partial[i]; add_reduce(b); }
+            if (c.dst) { c.n = n_slabs; c.src = thin.partial[i]; add_reduce(c); }
         }
         if (!partial) return 0;
         hipLaunchKernelGGL(thin_grad_kernel, dim3(n_slabs, n_thin), dim3(256), 0, stream, thin, P, slab);
         return check_launch("thin_grad (batched)");
-    }
-    // gb[f] = sum_p dA[p][f] (bias of a layer whose weights are all K = 3 columns)
-    int colsum(const float* dA, int lda, int F, float* gb) {
-        const int slabs = slabs_for(P, 1), slab = slab_pts_for(P, slabs);
-        const int n_slabs = (int)((P + slab - 1) / slab);
-        float* part = take((int64_t)n_slabs * 256);
-        add_reduce(ReduceJob{part, gb, nullptr, n_slabs, 256, 1, 256, 256, 0, 1, F, 0});
-        if (!partial) return 0;
-        hipLaunchKernelGGL(colsum_kernel, dim3(n_slabs), dim3(256), 0, stream, dA, lda, F, P, slab, part);
-        return check_launch("colsum");
     }
     int reduce_all() {
         if (!partial || !n_red) return 0;
@@ -1068,12 +1042,11 @@ static int batched_backward(int kind, BwdBatcher& b, const float* acts, float* g
             b.gemm<4, 2, 2>(b.g422, G(l), A(l), gp[2 * l], l == 5 ? 259 : 256, l == 5 ? 3 : 0, 256, 256, gp[2 * l + 1]);
         b.gemm<4, 2, 2>(b.g422, G(8), A(8), gp[16], 256, 0, 256, 256, gp[17]);                    // layers_dir.0 x X8
         b.gemm<4, 1, 2>(b.g412, G(9), A(9), gp[18], 259, 0, 128, 256, gp[19]);                    // layers_dir.1 x G
-        b.thin_job(A(0), 8, 0, 3, G(0), 256, 256, gp[0], 3, 0, true, nullptr);                    // layers_pos.0 (K = 3)
+        b.thin_job(A(0), 8, 0, 3, G(0), 256, 256, gp[0], 3, 0, true, nullptr, gp[1]);             // layers_pos.0 (K = 3) + its bias
         b.thin_job(A(0), 8, 0, 3, G(5), 256, 256, gp[10], 259, 0, true, nullptr);                 // skip layer's xyz columns
         b.thin_job(A(0), 8, 3, 3, G(9), 128, 128, gp[18], 259, 256, true, nullptr);               // layers_dir.1's dir columns
         b.thin_job(G(10), 4, 3, 1, A(8), 256, 256, gp[20], 256, 0, false, gp[21]);                // sigma head x X8
         b.thin_job(G(10), 4, 0, 3, A(10), 128, 128, gp[22], 128, 0, false, gp[23]);               // rgb head x X_d
-        if ((rc = b.colsum(G(0), 256, 256, gp[1]))) return rc;                                    // bias of layers_pos.0
     }
     if ((rc = b.flush<4, 2, 2>(b.g422))) return rc;
     if ((rc = b.flush<2, 2, 1>(b.g221))) return rc;
@@ -1163,10 +1136,9 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
             const auto jobs = [&](BwdBatcher& bb) -> int {
                 for (int l = 1; l <= 8; ++l)                                  // FiLM layer l: input X_{l-1} = acts region l
                     bb.gemm<4, 2, 2>(bb.g422, G(l), A(l), Tl(l), 256, 0, 256, 256, sl(l));
-                bb.thin_job(A(0), 8, 0, 3, G(0), 256, 256, T3_0, 3, 0, true, nullptr);              // input_layer (K = 3: xyz)
+                bb.thin_job(A(0), 8, 0, 3, G(0), 256, 256, T3_0, 3, 0, true, nullptr, s0);          // input_layer (K = 3: xyz) + s_0
                 if (use_dir) bb.thin_job(A(0), 8, 3, 3, G(8), 256, 256, T3_8, 3, 0, true, nullptr); // hidden_layer_rgb's dir columns
                 int r;
-                if ((r = bb.colsum(G(0), 256, 256, s0))) return r;
                 if ((r = bb.flush<4, 2, 2>(bb.g422))) return r;
                 if ((r = bb.flush_thin())) return r;
                 return bb.reduce_all();
