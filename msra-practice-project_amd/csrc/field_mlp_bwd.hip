@@ -176,8 +176,8 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
         if constexpr (KB == 8) {
             // 8 K blocks: the row traffic is spread over the whole layer (tools/probes/mfma_store_mix.hip: 8 + 8 quarters
-            // per K block from every CU at once run into the memory system's mixed read/write ceiling, half that
-            // density costs a quarter as much).  Loads: slots 0, 4, .., 20 of K blocks 0..5, decoded one K block
+            // per K block run into a mixed read/write ceiling - 80-110 cycles per instruction instead of 17-33 - and
+            // half that density costs a quarter as much).  Loads: slots 0, 4, .., 20 of K blocks 0..5, decoded one K block
             // later; deferred stores: slots 2, 6, 10, 14 of K blocks 0..7.
             if constexpr ((slot & 3) == 0) {
                 constexpr int jl = kb * 6 + slot / 4;

@@ -437,8 +437,8 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     };
     if constexpr (SAVE && PREV_MB > 0) {
         // a K block offers 3 * MB mid slots (2 * MB in the layer's last one): PPC quarters per K block on its odd slots
-        // (as thinly as the layer's K blocks allow: every fourth slot when 4 quarters per K block are enough - the row
-        // traffic of all CUs arrives in phase, see tools/probes/mfma_store_mix.hip)
+        // (as thinly as the layer's K blocks allow: every fourth slot when 4 quarters per K block are enough - dense row
+        // traffic costs several times more per instruction, see tools/probes/mfma_store_mix.hip)
         constexpr int PPC = MB >= 8 && KB * 4 < PREV_MB * 4 ? 8 : 4;
         constexpr int STRIDE = MB >= 8 && PPC == 4 ? 4 : 2;
         static_assert(KB * PPC >= PREV_MB * 4, "not enough K blocks to carry the previous layer's row quarters");

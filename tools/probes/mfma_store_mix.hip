@@ -8,8 +8,8 @@
 //   DMA  8 x 1 KiB buffer_load ... lds per wave in row 0 (the next weight stage)
 // 4 waves per CU, 256 CUs, 32 K blocks per wave.  Prints cycles per K block (8192 = pure MFMA issue).
 // Findings (profiles/r02_probe_mfma_store_mix.log): 8 stores or 8 loads per K block alone cost 17 / 33 cycles apiece, both
-// together 80-110 apiece wherever they sit in the K block (every CU issues them at the same time: 4.9 TB/s of demand
-// against the 4.1-4.4 TB/s of mixed traffic the memory system delivers), half the density a quarter of that; nontemporal
+// together 80-110 apiece wherever they sit in the K block (with every CU at that density: 4.9 TB/s of demand against
+// 4.1-4.4 TB/s of mixed traffic delivered), half the density a quarter of that; nontemporal
 // hints make it far worse; reading the first A operand of a group ahead of time recovers about half of the LDS cost.
 // The combined variants overstate what the real kernels pay (their rows run at 2 200-2 400 cycles): use them for
 // differences, not for absolute numbers.
