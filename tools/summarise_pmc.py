@@ -100,7 +100,9 @@ def train_summary(wl):
     stats = newest(f"prof_stats_{wl}/**/*kernel_stats.csv")
     if stats:
         shutil.copy(stats, os.path.join(out_dir, f"{tag}_bench_{wl}_kernel_stats.csv"))
-    log = os.path.join(ROOT, "gpurun_out", f"prof_stats_{wl}.log")
+    log = os.path.join(ROOT, "gpurun_out", f"bench_{wl}.log")              # the unprofiled run of tools/profile_round.sh
+    if not os.path.exists(log):
+        log = os.path.join(ROOT, "gpurun_out", f"prof_stats_{wl}.log")
     if os.path.exists(log):
         line = [l for l in open(log) if l.startswith("{")]
         if line:
