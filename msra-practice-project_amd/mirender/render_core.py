@@ -177,12 +177,41 @@ def render_video(width, height, focal, poses, near, far, coarse_model, fine_mode
     three values from the tensor-returning render_image): stacked NumPy frames rgb[F,H,W,3], depth[F,H,W,1],
     acc[F,H,W,1].  Keyword-only extras: `t_rand` [F, H*W, Nc] injects each frame's jitter, `seed` seeds frame i with
     seed + i (the reference draws every frame's jitter from the global RNG)."""
-    frames = []
+    # Frame i's three device->host copies run on a side stream into pinned memory while frame i + 1 renders (the
+    # reference - and render_image - stop for three pageable copies after every frame); at most two frames in flight.
+    poses = list(poses)
+    n, nframes = int(width) * int(height), len(poses)
+    if nframes == 0:
+        return (np.zeros((0, height, width, 3), np.float32), np.zeros((0, height, width, 1), np.float32),
+                np.zeros((0, height, width, 1), np.float32))
+    try:
+        host = [torch.empty((nframes, n, c), dtype=torch.float32, device="cpu", pin_memory=True) for c in (3, 1, 1)]
+    except RuntimeError:                       # no pinned memory to be had: pageable copies, still off the render stream
+        host = [torch.empty((nframes, n, c), dtype=torch.float32, device="cpu") for c in (3, 1, 1)]
+    copy_stream, done = None, []
     for i, p in enumerate(tqdm(poses)):
-        frames.append(render_image(width, height, focal, p, near, far, coarse_model, fine_model, coarse_sample_num,
-                                   fine_sample_num, chunk, t_rand=None if t_rand is None else t_rand[i],
-                                   seed=None if seed is None else seed + i))
-    return tuple(np.stack([f[k] for f in frames]) for k in range(3))
+        with torch.no_grad():
+            outs = _render_image_device(width, height, focal, p, near, far, coarse_model, fine_model,
+                                        int(coarse_sample_num), int(fine_sample_num), None,
+                                        None if t_rand is None else t_rand[i], None if seed is None else seed + i)
+        dev = outs[0].device
+        if copy_stream is None:
+            copy_stream = torch.cuda.Stream(dev)
+        rendered = torch.cuda.Event()
+        rendered.record(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(rendered)
+            for h, t in zip(host, outs):
+                h[i].copy_(t.reshape(n, -1), non_blocking=True)
+                t.record_stream(copy_stream)   # the allocator must not hand the frame out again before its copy ran
+            copied = torch.cuda.Event()
+            copied.record(copy_stream)
+        done.append(copied)
+        if len(done) > 1:
+            done.pop(0).synchronize()
+    copy_stream.synchronize()
+    return (host[0].numpy().reshape(nframes, height, width, 3), host[1].numpy().reshape(nframes, height, width, 1),
+            host[2].numpy().reshape(nframes, height, width, 1))
 
 
 render_video_np = render_video

@@ -459,3 +459,22 @@ def test_render_video_and_image_np_golden(nerf_render, pigan_render, golden):
     b = nerf_render.render_video(W, H, focal, poses, near, far, cm, fm, nc, nf, seed=5)
     c = nerf_render.render_image(W, H, focal, poses[1], near, far, cm, fm, nc, nf, seed=6)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[0][1], c[0])
+
+
+def test_render_video_overlaps_copies_without_mixing_frames(nerf_render):
+    """render_video copies frame i to the host on a side stream while frame i + 1 renders: seven frames (more than the
+    two kept in flight) must each be the bytes render_image gives for that pose and seed; no poses -> empty stacks."""
+    W, H, nc, nf = 64, 48, 16, 16
+    cm = model("tiny_nerf", synth.state_dict("tiny_nerf", seed=70, sharp="medium", bias_jitter=0.05))
+    fm = model("tiny_nerf", synth.state_dict("tiny_nerf", seed=71, sharp="medium", bias_jitter=0.05))
+    poses = [synth.pose_degrees(4.0, float(a), -30.0) for a in np.linspace(-150, 150, 7)]
+    vid = nerf_render.render_video(W, H, 1.3875 * W, poses, 2.0, 6.0, cm, fm, nc, nf, seed=40)
+    assert [v.shape for v in vid] == [(7, H, W, 3), (7, H, W, 1), (7, H, W, 1)]
+    for i, pose in enumerate(poses):
+        one = nerf_render.render_image(W, H, 1.3875 * W, pose, 2.0, 6.0, cm, fm, nc, nf, seed=40 + i)
+        for k in range(3):
+            assert np.array_equal(one[k], vid[k][i]), (i, k)
+    assert len({vid[0][i].tobytes() for i in range(7)}) == 7          # seven different frames
+    empty = nerf_render.render_video(W, H, 1.3875 * W, [], 2.0, 6.0, cm, fm, nc, nf)
+    assert [v.shape for v in empty] == [(0, H, W, 3), (0, H, W, 1), (0, H, W, 1)]
+
