@@ -184,8 +184,9 @@ def render_video(width, height, focal, poses, near, far, coarse_model, fine_mode
     if nframes == 0:
         return (np.zeros((0, height, width, 3), np.float32), np.zeros((0, height, width, 1), np.float32),
                 np.zeros((0, height, width, 1), np.float32))
+    pin = nframes * n * 20 <= (2 << 30)        # page-locking more than 2 GiB for one call is not ours to decide
     try:
-        host = [torch.empty((nframes, n, c), dtype=torch.float32, device="cpu", pin_memory=True) for c in (3, 1, 1)]
+        host = [torch.empty((nframes, n, c), dtype=torch.float32, device="cpu", pin_memory=pin) for c in (3, 1, 1)]
     except RuntimeError:                       # no pinned memory to be had: pageable copies, still off the render stream
         host = [torch.empty((nframes, n, c), dtype=torch.float32, device="cpu") for c in (3, 1, 1)]
     copy_stream, done = None, []
