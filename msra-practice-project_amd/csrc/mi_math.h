@@ -83,17 +83,23 @@ __device__ __forceinline__ f32x2 hw_sin30_x2(f32x2 u) {
 
 // Training: what the backward needs of a sin layer is its output X = sin(30 u) (the next layer's dW operand) and the
 // derivative factor C = 30 cos(30 u).  Only X is kept, with the SIGN of the cosine in its lowest mantissa bit
-// (the reduced angle r is at hand: cos < 0 iff |r| > 1/4 turn), and the backward rebuilds
+// (the reduced angle r is at hand: cos < 0 iff |r| > 1/4 turn, see cos_sign_into), and the backward rebuilds
 // C = +-30 sqrt(1 - X^2).  Halves the saved bytes per point (18.5 -> 9.3 KB for the FiLM field) and saves the v_cos.
 // Cost in accuracy: X' differs from X by <= 1 ulp (6e-8 relative, below the dW GEMM's own rounding), and the rebuilt
 // |cos| carries X's 2e-7 error amplified by |X|/|cos|: more than 2e-4 absolute only where |cos| < 1e-3, i.e. for
 // 0.06 % of the units - 2e-5 of the factor's RMS, against the 5e-4 relative gate on every gradient tensor.
+// The bit without a compare: cos(2 pi r) < 0 iff rndne(2 r) is odd (r in [-1/2, 1/2]); adding 1.5 * 2^23 rounds 2 r to
+// that integer in the low mantissa bits, and one v_bfi_b32 moves its parity into X - two instructions instead of a
+// compare, a select and an and-or.
+__device__ __forceinline__ float cos_sign_into(float sn, float r) {
+    const float y = fmaf(r, 2.f, 12582912.f);
+    return __uint_as_float((__float_as_uint(sn) & ~1u) | (__float_as_uint(y) & 1u));
+}
 struct SinSaved { float s, saved; };
 __device__ __forceinline__ SinSaved hw_sin30_saved(float u) {
     const float r = hw_turns30(u);
     const float sn = __builtin_amdgcn_sinf(r);
-    const unsigned neg = fabsf(r) > 0.25f ? 1u : 0u;
-    return {sn, __uint_as_float((__float_as_uint(sn) & ~1u) | neg)};
+    return {sn, cos_sign_into(sn, r)};
 }
 __device__ __forceinline__ float dsin30_from_saved(float xs) {
     // 900 (1 - X^2); |X| <= 1 makes it non-negative, and the |.| (a free source modifier of v_sqrt) keeps a
@@ -108,8 +114,8 @@ __device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {
     const f32x2 sn = {__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y)};
     SinSaved2 o;
     o.s = sn;
-    o.saved.x = __uint_as_float((__float_as_uint(sn.x) & ~1u) | (fabsf(r.x) > 0.25f ? 1u : 0u));
-    o.saved.y = __uint_as_float((__float_as_uint(sn.y) & ~1u) | (fabsf(r.y) > 0.25f ? 1u : 0u));
+    o.saved.x = cos_sign_into(sn.x, r.x);
+    o.saved.y = cos_sign_into(sn.y, r.y);
     return o;
 }
 
