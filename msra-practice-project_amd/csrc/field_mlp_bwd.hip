@@ -887,10 +887,11 @@ int64_t film_partial_floats(int64_t /*n_groups*/, int64_t /*points_per_group*/) 
 
 static int64_t batched_partial_floats(int kind, int64_t P);
 int64_t bwd_partial_floats(int64_t P) {
-    // FiLM kinds: one image at a time - eight GEMM jobs of at most 32 slabs each, two thin jobs, a column sum (or the
-    // two head jobs over all images): an upper bound whatever the image size.  launch_field_backward checks every
+    // FiLM kinds: one image at a time - eight GEMM jobs of at most 32 slabs each, two thin jobs (or the two head
+    // jobs over all images): an upper bound for any image of at most P points.  launch_field_backward checks every
     // pass's real plan against this figure before it launches anything.
-    int64_t most = (int64_t)8 * 32 * kFilmLayerScratch + 2 * 128 * 1280 + 256 * 256 + 4096;
+    const int64_t slabs256 = (P + 255) / 256 > 0 ? (P + 255) / 256 : 1;          // BwdBatcher::slabs_for never exceeds this
+    int64_t most = 8 * (slabs256 < 32 ? slabs256 : 32) * kFilmLayerScratch + 2 * (slabs256 < 128 ? slabs256 : 128) * 1280 + 4096;
     for (int kind : {0, 1, 4}) {                                       // the others: every job of the pass at once
         const int64_t n = batched_partial_floats(kind, P);
         if (n > most) most = n;
