@@ -27,6 +27,28 @@ __constant__ PackTable c_bwd[5] = {build_nerf_bwd(), build_siren_nerf_bwd(), bui
                                    build_tiny_nerf_bwd()};
 
 constexpr int kAdamMaxParams = 48;      // two fields of up to 24 tensors
+constexpr int kAdamMaxHits = 16;        // stream items per parameter tensor the kernel's hit lists hold
+
+// The hit lists are sized by a constant, the tables by field_layout.h: tie the two at compile time, so a layout change
+// that puts a tensor into more items than the lists hold cannot leave stream positions silently stale.
+constexpr int max_items_per_param(const PackTable& t) {
+    int worst = 0;
+    for (int prm = 0; prm < kAdamMaxParams; ++prm) {       // a field has at most 24 tensors
+        int n = 0;
+        for (int i = 0; i < t.n_items; ++i) n += t.item[i].param == prm;
+        worst = n > worst ? n : worst;
+    }
+    return worst;
+}
+constexpr int max_items_per_param_all() {
+    const PackTable all[10] = {build_nerf(), build_siren_nerf(), build_film(true), build_film(false), build_tiny_nerf(),
+                               build_nerf_bwd(), build_siren_nerf_bwd(), build_film_bwd(true), build_film_bwd(false),
+                               build_tiny_nerf_bwd()};
+    int worst = 0;
+    for (int k = 0; k < 10; ++k) { const int n = max_items_per_param(all[k]); worst = n > worst ? n : worst; }
+    return worst;
+}
+static_assert(max_items_per_param_all() <= kAdamMaxHits, "adam_pack_kernel: a parameter sits in more stream items than hit_f / hit_b hold");
 struct AdamArgs {
     float* p[kAdamMaxParams];
     const float* g[kAdamMaxParams];
@@ -72,16 +94,16 @@ __global__ __launch_bounds__(256) void adam_pack_kernel(AdamArgs a) {
     // walking both 100-item tables per ELEMENT cost 130 us on a 1.2 M-parameter step)
     // (thread i looks at item i of each table; the order of the hits does not matter, every hit writes its own positions)
     if (blockIdx.x * 256 >= n) return;                           // the grid is sized for the largest tensor
-    __shared__ int hit_f[16], hit_b[16], n_hit[2];
+    __shared__ int hit_f[kAdamMaxHits], hit_b[kAdamMaxHits], n_hit[2];
     if (threadIdx.x < 2) n_hit[threadIdx.x] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < tf.n_items; i += 256)
-        if (tf.item[i].param == prm) { const int k = atomicAdd(&n_hit[0], 1); if (k < 16) hit_f[k] = i; }
+        if (tf.item[i].param == prm) { const int k = atomicAdd(&n_hit[0], 1); if (k < kAdamMaxHits) hit_f[k] = i; }
     if (pb)
         for (int i = threadIdx.x; i < tb.n_items; i += 256)
-            if (tb.item[i].param == prm) { const int k = atomicAdd(&n_hit[1], 1); if (k < 16) hit_b[k] = i; }
+            if (tb.item[i].param == prm) { const int k = atomicAdd(&n_hit[1], 1); if (k < kAdamMaxHits) hit_b[k] = i; }
     __syncthreads();
-    const int nf = n_hit[0] < 16 ? n_hit[0] : 16, nb = n_hit[1] < 16 ? n_hit[1] : 16;
+    const int nf = n_hit[0], nb = n_hit[1];                      // <= kAdamMaxHits by the static_assert above
     for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         const float g = a.g[t][e];
         float m = a.m[t][e], v = a.v[t][e], p = a.p[t][e];
@@ -119,6 +141,11 @@ int launch_adam_step(int n_fields, const int* kinds, const int* n_params, float*
             if (numel[t] > 0x7fffffff) { set_error("mi_adam_step: tensor too large"); return -1; }
             a.p[t] = params[t]; a.g[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t];
             a.numel[t] = (int)numel[t]; a.field[t] = f; a.index[t] = i;
+            if (!(i & 1) && (numel[t + 1] <= 0 || numel[t] % numel[t + 1] != 0)) {
+                set_error("mi_adam_step: tensor %d (%lld elements) is not a [out, in] weight of the bias that follows it (%lld)",
+                          t, (long long)numel[t], (long long)numel[t + 1]);
+                return -1;
+            }
             a.in_f[t] = (i & 1) ? 1 : (int)(numel[t] / numel[t + 1]);          // weight [out, in] is followed by its bias [out]
             if (numel[t] > most) most = numel[t];
         }

@@ -51,18 +51,28 @@ def build_profile(verbose=True):
     return out
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, always=()):
+    """Compile what is stale (everything with force; the translation units named in `always` regardless) and link.
+    Prints, per translation unit, whether it was COMPILED or REUSED - the record of what a given run of the build
+    check really exercised - and returns the library's path."""
+    import time
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs, jobs = [], []
+    t_start = time.time()
     for src, extra in SOURCES.items():
         s = os.path.join(HERE, src)
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        why = "forced" if force else "always rebuilt by the build check" if src in always else \
+            "no object yet" if not os.path.exists(o) else "source or header newer than the object" if _stale(o, [s] + hdrs) else None
+        if why:
             jobs.append([hipcc, *COMMON, *extra, "-c", s, "-o", o])
+            print(f"[build] {src}: COMPILED for {ARCH} ({why})", flush=True)
+        else:
+            print(f"[build] {src}: REUSED {os.path.relpath(o, PKG)} (newer than its source and every header)", flush=True)
     # the translation units are independent (the two MLP files take minutes each): compile them side by side
     from concurrent.futures import ThreadPoolExecutor
 
@@ -77,6 +87,10 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        print(f"[build] {os.path.relpath(OUT, PKG)}: LINKED", flush=True)
+    else:
+        print(f"[build] {os.path.relpath(OUT, PKG)}: REUSED (newer than every object)", flush=True)
+    print(f"[build] {len(jobs)} of {len(SOURCES)} translation units compiled in {time.time() - t_start:.0f} s", flush=True)
     return OUT
 
 

@@ -19,8 +19,8 @@ from . import _lib, fields, ops
 CHUNK_BYTES = 48 << 30         # saved activations + per-layer gradients per ray range (288 GB of HBM)
 SAVE_COARSE_BYTES = 48 << 30   # layer inputs the forward may keep for the coarse pass (no recompute in backward) ...
 SAVE_FINE_BYTES = 208 << 30    # ... and for the fine pass; both also limited to the free memory minus RESERVE_BYTES
-RESERVE_BYTES = CHUNK_BYTES + (16 << 30)   # what backward needs besides the kept inputs: one range's recomputed inputs
-#                                            + gradients (CHUNK_BYTES by construction), reduction scratch, raw / depths
+RESERVE_FIXED_BYTES = 16 << 30   # what backward needs besides the kept inputs and one range's rows: reduction scratch,
+#                                  raw / depths / their gradients, the allocator's rounding
 
 
 # MI_DEBUG_GUARDS=1 (tests/test_gpu_guards.py): every scratch / row buffer handed to the library gets GUARD extra floats of a
@@ -99,12 +99,17 @@ def _film_of_range(f_all, rpg, r0, r1):
     return f_all[r0 // rpg:max(r0 // rpg + 1, r1 // rpg)]
 
 
-def _save_budget(dev, cap: int) -> int:
-    """Bytes of layer inputs the forward may keep: `cap`, but never more than what is free right now (the driver's
-    figure plus what torch's caching allocator holds unused) minus RESERVE_BYTES."""
+def _save_budget(dev, cap: int, range_bytes: int) -> int:
+    """Bytes of layer inputs the forward may keep: `cap`, but never more than what can really be had right now minus
+    what backward will ask for on top - one range's recomputed inputs + per-layer gradients (`range_bytes`, the largest
+    range of THIS pass, not the CHUNK_BYTES ceiling) + RESERVE_FIXED_BYTES.  "Can be had" = the driver's free figure
+    plus the part of torch's cache that is whole free segments; the unused remainders of partly used segments
+    (`inactive_split_bytes`) cannot be handed back to the driver or merged, so they do not count."""
     free, _total = torch.cuda.mem_get_info(dev)
+    stats = torch.cuda.memory_stats(dev)
     cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
-    return max(0, min(cap, free + cached - RESERVE_BYTES))
+    cached -= stats.get("inactive_split_bytes.all.current", 0)
+    return max(0, min(cap, free + max(0, cached) - range_bytes - RESERVE_FIXED_BYTES))
 
 
 def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothing: bool = False):
@@ -115,7 +120,8 @@ def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothin
     n, s = z.shape
     per_point = 4 * lib.mi_field_train_acts_floats(pf.kind)
     f_all, rpg, ranges = _chunk_ranges(pf, n, s, film)
-    budget = _save_budget(pf.device, cap)
+    per_point_bwd = per_point + 4 * lib.mi_field_train_grads_floats(pf.kind)
+    budget = _save_budget(pf.device, cap, per_point_bwd * s * max(r1 - r0 for r0, r1 in ranges))
     if all_or_nothing and per_point * n * s > budget:
         budget = 0
     saved, parts, r_done = {}, [], 0
@@ -151,10 +157,11 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
     g_film = None if f_all is None else torch.empty_like(f_all)
     packed_bwd = pf.refresh_bwd()
     stream = _lib.stream_ptr(dev)
-    for k, (r0, r1) in enumerate(ranges):
+    def one_range(k, r0, r1):
         pts = (r1 - r0) * s
         f_c = g_c = fp = None
         ng, ppg = 1, pts
+        add_to_row, g0 = False, 0
         if f_all is not None:
             f_c = _film_of_range(f_all, rpg, r0, r1)
             ng = f_c.shape[0]
@@ -165,13 +172,13 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
             add_to_row = part_of_group and r0 % rpg != 0
             g_c = torch.empty_like(f_c) if add_to_row else g_film[g0:g0 + ng]
             fp = torch.empty(lib.mi_field_film_partial_floats(ng, ppg), dtype=torch.float32, device=dev)
+        gws, gws_g = _guarded(grads_f * pts, dev)
+        part, part_g = _guarded(lib.mi_field_bwd_partial_floats(pts), dev)
+        out = [torch.empty_like(p) for p in pf.params]
         if k in saved:
             acts_c, raw_c = saved.pop(k), raw[r0:r1]
         else:
             raw_c, acts_c = _forward_saving(pf, rays[r0:r1], z[r0:r1], f_c)
-        gws, gws_g = _guarded(grads_f * pts, dev)
-        part, part_g = _guarded(lib.mi_field_bwd_partial_floats(pts), dev)
-        out = [torch.empty_like(p) for p in pf.params]
         arr = (ctypes.c_void_p * len(out))(*[t.data_ptr() for t in out])
         # FiLM kinds: d gamma = <W, dW_image> + b . db_image needs the parameters themselves
         par = (ctypes.c_void_p * len(out))(*[p.data_ptr() for p in pf.params]) if f_all is not None else None
@@ -184,6 +191,21 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
         _check_guard(part_g, "backward scratch (mi_field_bwd_partial_floats)")
         if f_all is not None and add_to_row:
             g_film[g0:g0 + 1] += g_c
+        return out
+
+    for k, (r0, r1) in enumerate(ranges):
+        try:
+            out = one_range(k, r0, r1)
+        except torch.cuda.OutOfMemoryError:
+            # The forward kept more layer inputs than this backward can live next to (its budget is an estimate of what
+            # the allocator can still give).  Nothing of range k has been launched yet - allocations come first in
+            # one_range - so give the kept inputs of the ranges still ahead back, and recompute them range by range:
+            # same gradients bit for bit (tests/test_gpu_train.py), bounded memory.
+            if not saved:
+                raise
+            saved.clear()
+            torch.cuda.empty_cache()
+            out = one_range(k, r0, r1)
         if total is None:
             total = out
         else:

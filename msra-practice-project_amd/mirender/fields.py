@@ -74,6 +74,72 @@ def detect_kind(named_params: dict) -> int | None:
     return None
 
 
+W_0 = 30.0     # the one frequency the sin kernels implement (nerf/nerf.py:112 hard-codes it; FilmSiren's default, modules.py:11)
+
+
+def expected_activation(kind: int, key: str) -> str:
+    """What the fused kernel of `kind` applies after layer `key`: "relu" | "linear" | "sigmoid" (Dense's names,
+    nerf/nerf.py:15-16), "sin" (Siren, nerf/nerf.py:111-112) or "film" (FilmSiren, pi_GAN/modules.py:22-25)."""
+    if key.startswith("output_layer_sigma"):
+        return "relu"
+    if key.startswith("output_layer_rgb"):
+        return "sigmoid"
+    if is_film(kind):
+        return "film"
+    if key == "layers_dir.0" and kind != TINY_NERF:
+        return "linear"
+    return "sin" if kind == SIREN_NERF else "relu"
+
+
+def _layer_module(model, key):
+    mod = model
+    for part in key.split("."):
+        mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+    return mod
+
+
+def hyper_mismatch(model, kind: int) -> str | None:
+    """A layout match is not enough: the kernels hard-code each layer's activation and w_0 = 30.  Walk the layer
+    objects of a recognised module and compare what they say about themselves with what the kernel of `kind`
+    computes; returns a description of the first mismatch (the caller then takes the generic path, which calls the
+    module's own forward), or None.
+
+      Dense       (nerf/nerf.py:5-28)        carries `activation_name`
+      FilmSiren   (pi_GAN/modules.py:8-31)   carries `w_0` (and is only right for the "film" slots)
+      Siren       (nerf/nerf.py:97-117)      carries neither: recognised by its class name, sin(30 .) hard-coded there
+      nn.Linear inside nn.Sequential(Linear, ReLU|Sigmoid)  (modules.py:81-84,89-92): the sibling names the activation
+      our own leaves (`_Leaf`)               carry `mi_activation`
+    Anything else (a user's nn.Linear stack with its own forward, a subclass with another nonlinearity) says nothing
+    about its activation, so it is not claimed."""
+    for key, _ in SPECS[kind]:
+        want = expected_activation(kind, key)
+        try:
+            mod = _layer_module(model, key)
+        except (AttributeError, IndexError, KeyError, TypeError):
+            return f"{key}: no such layer object"
+        if hasattr(mod, "mi_activation"):
+            have = mod.mi_activation
+        elif hasattr(mod, "activation_name"):
+            have = mod.activation_name
+        elif hasattr(mod, "w_0"):
+            if float(mod.w_0) != W_0:
+                return f"{key}: w_0 = {mod.w_0} (the fused kernels implement w_0 = {W_0:g} only)"
+            have = "film"
+        elif type(mod).__name__ == "Siren":
+            have = "sin"
+        elif type(mod) is torch.nn.Linear and key.endswith(".0"):
+            try:
+                sib = _layer_module(model, key[:-2])[1]
+            except (AttributeError, IndexError, KeyError, TypeError):
+                return f"{key}: a bare Linear with no activation module after it"
+            have = {"ReLU": "relu", "Sigmoid": "sigmoid"}.get(type(sib).__name__, type(sib).__name__)
+        else:
+            return f"{key}: {type(mod).__name__} does not name its activation"
+        if have != want:
+            return f"{key}: activation {have!r}, the fused {KIND_NAMES[kind]} kernel applies {want!r}"
+    return None
+
+
 class PackedField:
     """Packed MFMA-ordered weights of one model, refreshed lazily from its live parameters."""
 
@@ -81,6 +147,7 @@ class PackedField:
         self.kind = kind
         self.params = params                      # live tensors, state-dict order (w0,b0,w1,b1,...)
         self.device = None
+        self._epoch = 0                           # bumped by writers that bypass the version counters (FusedAdam)
         self._follow_device()
 
     def _follow_device(self):
@@ -101,7 +168,18 @@ class PackedField:
         In-place updates through torch ops (optimiser steps, load_state_dict, `p.mul_()` under no_grad) bump the
         counter; writes through `.data` (the reference's `bias.data[:n] = 1`, pi_GAN/modules.py:57-58) do NOT -
         call invalidate() after such a write."""
-        return tuple((p.data_ptr(), p._version) for p in self.params)
+        return (self._epoch,) + tuple((p.data_ptr(), p._version) for p in self.params)
+
+    def note_fused_update(self):
+        """A kernel rewrote the parameters AND every existing packed stream consistently (mirender.train.FusedAdam):
+        the streams stay valid - they are re-stamped - but anything that remembered `versions()` from before (a forward
+        whose backward has not run yet: autograd._RenderRaysFn) must see that the weights moved."""
+        self._epoch += 1
+        vers = self.versions()
+        if self._versions is not None:
+            self._versions = vers
+        if self._versions_bwd is not None:
+            self._versions_bwd = vers
 
     def invalidate(self):
         """Force a repack on the next use (after writes the version counters cannot see, e.g. through `.data`)."""
@@ -184,6 +262,8 @@ def as_packed_field(model) -> PackedField | None:
         if not named and getattr(model, "_is_replica", False):
             named = _replica_named(model)
         kind = detect_kind(named)
+        if kind is not None and hyper_mismatch(model, kind) is not None:
+            kind = None            # same layout, other arithmetic (w_0 != 30, another activation): generic path
         if kind is None:
             _field_cache[model] = False
             return None
@@ -234,6 +314,14 @@ def eval_points(pf: PackedField, x: torch.Tensor, film: torch.Tensor | None = No
 # ------------------------------------------------------------------------------------------
 # nn.Module families with the reference's state-dict layout and initialisers
 # ------------------------------------------------------------------------------------------
+class _Leaf(torch.nn.Module):
+    """One linear layer's parameters; `mi_activation` names what the fused kernel applies after it."""
+
+    def __init__(self, activation: str):
+        super().__init__()
+        self.mi_activation = activation
+
+
 class _FusedField(torch.nn.Module):
     KIND = None
 
@@ -245,7 +333,7 @@ class _FusedField(torch.nn.Module):
 
     def _register(self, key, w, b):
         # "layers_pos.3" -> self.layers_pos (ModuleList, indexable like the reference's) [3]
-        leaf = torch.nn.Module()
+        leaf = _Leaf(expected_activation(self.KIND, key))
         leaf.weight, leaf.bias = w, b
         parts = key.split(".")
         if len(parts) == 1:

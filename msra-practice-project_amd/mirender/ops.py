@@ -158,12 +158,21 @@ class _Workspace:
     def release(cls, device=None):
         """Drop the scratch of `device` (all devices if None): it only grows otherwise (3.4 GB after an 800x800 frame).
         Safe at any time between calls; the next render_rays allocates what it needs."""
-        for key in [k for k in cls.bufs if device is None or k[0] == str(device)]:
+        want = None if device is None else cls._name(device)
+        for key in [k for k in cls.bufs if want is None or k[0] == want]:
             del cls.bufs[key]
+
+    @staticmethod
+    def _name(device) -> str:
+        """'cuda', 'cuda:0', torch.device('cuda'), 0 -> 'cuda:<index>' (the current device where none is given)."""
+        d = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if d.type == "cuda" and d.index is None:
+            d = torch.device("cuda", torch.cuda.current_device())
+        return str(d)
 
     @classmethod
     def get(cls, device, nbytes):
-        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        key = (cls._name(device), torch.cuda.current_stream(device).cuda_stream)
         b = cls.bufs.get(key)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(nbytes), dtype=torch.uint8, device=device)

@@ -167,11 +167,17 @@ class FusedAdam:
         bc1 = 1 - beta1 ** t
         bc2_sqrt = math.sqrt(1 - beta2 ** t)
         n = len(self.params)
+        for pf in self.fields:
+            pf._follow_device()                    # `model.to(other_device)` after construction re-homes the streams
         dev = self.fields[0].device
         grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in self.params]
         for p, gr in zip(self.params, grads):
-            if not p.is_contiguous() or gr.dtype != torch.float32 or gr.device != p.device:
-                raise _lib.MiRenderError("FusedAdam: parameters and gradients must be contiguous fp32 on one device")
+            if not p.is_contiguous() or gr.dtype != torch.float32 or p.device != dev or gr.device != dev:
+                raise _lib.MiRenderError("FusedAdam: parameters and gradients must be contiguous fp32 on one device "
+                                         f"({dev}); got a parameter on {p.device} with its gradient on {gr.device}")
+            st = self.state[p]
+            if st["exp_avg"].device != dev:        # the moments follow the parameters (raw pointers go to the kernel)
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].to(dev), st["exp_avg_sq"].to(dev)
         arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])  # noqa: E731
         kinds = (ctypes.c_int * len(self.fields))(*[pf.kind for pf in self.fields])
         numel = (ctypes.c_int64 * n)(*[p.numel() for p in self.params])
@@ -188,8 +194,12 @@ class FusedAdam:
                                         _lib.stream_ptr(dev)), "mi_adam_step")
         for p in self.params:
             self.state[p]["step"] += 1
-        # the kernel wrote parameters and streams together; the version counters did not move, so the lazily
-        # refreshed streams stay valid.  (A stream that did not exist yet is built from the parameters on first use.)
+        # the kernel wrote parameters and streams together; torch's version counters did not move, so the lazily
+        # refreshed streams stay valid (re-stamped), while the field's own epoch tells a forward that is still waiting
+        # for its backward that the weights changed under it (autograd._RenderRaysFn.backward raises, as PyTorch does
+        # for its own saved tensors).  A stream that did not exist yet is built from the parameters on first use.
+        for pf in self.fields:
+            pf.note_fused_update()
 
     # -- torch.optim.Adam's state-dict format ------------------------------------------------------------------
     def state_dict(self):

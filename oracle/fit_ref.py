@@ -23,6 +23,10 @@ class Scene:
     def __init__(self, res=24, n_views=6, nc=16, nf=16, seed=100, student="tiny_nerf"):
         self.res, self.nc, self.nf, self.student = res, nc, nf, student
         self.focal = 1.3875 * res
+        # FiLM students: one fixed FiLM row [9,512] (a single "image" of the mapping network's output, gamma ~ 1,
+        # beta ~ 0: pi_GAN/modules.py:56-58) shared by every ray - the field alone is trained, as synthesis.py:83-107
+        # trains through a fixed generator
+        self.film = synth.film_params(1, seed=seed + 3)[0] if student.startswith("film") else None
         sd_t = synth.state_dict("tiny_nerf", seed=seed, sharp="medium", bias_jitter=0.05)
         teacher = ofields.make_field("tiny_nerf", sd_t)
         angles = list(np.linspace(-150.0, 150.0, n_views)) + [17.0]
@@ -42,6 +46,8 @@ class Scene:
     def batch(self, step: int, batch_size: int):
         """Deterministic batches: a fixed permutation of all training rays, walked in order (train_nerf.py:140-147)."""
         n = self.train_rays.shape[0]
+        if not batch_size:
+            return self.train_rays, self.train_rgb, synth.t_rand(n, self.nc, seed=90000 + step)
         perm = np.random.Generator(np.random.PCG64(4242)).permutation(n)
         idx = torch.from_numpy(perm[(step * batch_size) % n:][:batch_size].copy())
         if idx.numel() < batch_size:
@@ -56,17 +62,28 @@ def lr_at(step, lr0=5e-4, decay=250):
     return lr0 * (0.1 ** (step / (decay * 1000)))            # train_nerf.py:170-173
 
 
-def fit_cpu(scene: Scene, steps: int, batch_size: int, f64: bool = False):
+def make_optimizer(params, optimizer: str, lr0: float):
+    """"adam": torch.optim.Adam as train_nerf.py:98 builds it.  "sgd": plain gradient descent - Adam's first updates are
+    m/sqrt(v) = +-1 per element whatever the gradient's size, so only a loop whose step is PROPORTIONAL to the gradient
+    shows a gradient of the wrong magnitude in the next step's loss."""
+    if optimizer == "sgd":
+        return torch.optim.SGD(params, lr=lr0)
+    return torch.optim.Adam(params, lr=lr0, betas=(0.9, 0.999))
+
+
+def fit_cpu(scene: Scene, steps: int, batch_size: int, f64: bool = False, lr0: float = 5e-4, optimizer: str = "adam"):
     """The reference loop on CPU autograd through the oracle.  Returns (losses[steps], heldout_psnr, state dicts).
     f64: the same loop with weights, activations and optimiser state in double - how far apart two correct
-    implementations of this loop may drift (sin networks amplify rounding differences from the first Adam steps on)."""
+    implementations of this loop may drift (sin networks amplify rounding differences from the first Adam steps on).
+    batch_size 0: every training ray in every step (no batching noise: the quietest regime of the loop)."""
     cast = (lambda v: v.double()) if f64 else (lambda v: v)
     sd_c = {k: cast(v).clone().requires_grad_(True) for k, v in scene.student_init[0].items()}
     sd_f = {k: cast(v).clone().requires_grad_(True) for k, v in scene.student_init[1].items()}
-    fc, ff = ofields.make_field(scene.student, sd_c), ofields.make_field(scene.student, sd_f)
+    film = None if scene.film is None else cast(scene.film)
+    fc, ff = ofields.make_field(scene.student, sd_c, film), ofields.make_field(scene.student, sd_f, film)
     render = R.render_rays_f64 if f64 else R.render_rays
     params = list(sd_c.values()) + list(sd_f.values())
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))                # train_nerf.py:98
+    opt = make_optimizer(params, optimizer, lr0)
     losses = []
     for step in range(steps):
         rays, rgb, tr = scene.batch(step, batch_size)
@@ -77,7 +94,7 @@ def fit_cpu(scene: Scene, steps: int, batch_size: int, f64: bool = False):
         loss.backward()
         opt.step()
         for g in opt.param_groups:
-            g["lr"] = lr_at(step + 1)
+            g["lr"] = lr_at(step + 1, lr0)
         losses.append(float(loss.detach()))
     with torch.no_grad():
         held = render(scene.rays[-1], NEAR, FAR, fc, ff, scene.nc, scene.nf, scene.heldout_jitter())

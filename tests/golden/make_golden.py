@@ -17,6 +17,7 @@ Fixture families:
   F7 nerf_grad     nerf training loss grads for one ray batch
   F8 metrics       pytorch_ssim.ssim / mse / psnr of synthetic frame pairs (nerf/test_nerf.py:102-104)
   F9 video         render_video / render_image / render_image_np over two poses; ref_layouts.json (make_r02)
+  ref_layer_attrs.json   each layer object's class / activation_name / w_0 in the reference's field classes (make_r03)
 """
 import contextlib
 import os
@@ -266,12 +267,47 @@ def make_r02(nr, nm, nd, pr, pm):
     print("ref_layouts.json", {k: len(v) for k, v in out.items()})
 
 
+def make_r03(nm, pm):
+    """ref_layer_attrs.json: what every layer object of the reference's field classes says about itself - class name,
+    Dense.activation_name (nerf/nerf.py:15), FilmSiren.w_0 (pi_GAN/modules.py:15), and for a Linear inside a
+    Sequential the class of the module after it (modules.py:81-84,89-92) - keyed like the state dict.  Data only;
+    fields.hyper_mismatch is tested against it (tests/test_host_logic.py)."""
+    import json
+    models = {
+        "nerf.NeRF": ("nerf", nm.NeRF()), "nerf.SirenNeRF": ("siren_nerf", nm.SirenNeRF()),
+        "pi_GAN.FilmSirenNeRF(use_dir=True)": ("film_siren_nerf", pm.FilmSirenNeRF(use_dir=True)),
+        "pi_GAN.FilmSirenNeRF(use_dir=False)": ("film_siren_nerf_nodir", pm.FilmSirenNeRF(use_dir=False)),
+        "pi_GAN.FilmSirenNeRF(w_0=25)": ("film_siren_nerf", pm.FilmSirenNeRF(w_0=25)),
+    }
+    out = {}
+    for name, (kind, m) in models.items():
+        layers = {}
+        for key, _ in SPECS[kind]:
+            mod = m
+            for part in key.split("."):
+                mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+            rec = {"class": type(mod).__name__}
+            for attr in ("activation_name", "w_0"):
+                if hasattr(mod, attr):
+                    rec[attr] = getattr(mod, attr)
+            if key.endswith(".0") and isinstance(getattr(m, key[:-2], None), torch.nn.Sequential):
+                rec["next_in_sequential"] = type(getattr(m, key[:-2])[1]).__name__
+            layers[key] = rec
+        out[name] = {"kind": kind, "layers": layers}
+    with open(os.path.join(HERE, "ref_layer_attrs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("ref_layer_attrs.json", {k: len(v["layers"]) for k, v in out.items()})
+
+
 def main():
     if "--only-metrics" in sys.argv:
         make_metrics()
         return
     torch.set_num_threads(8)
     nr, nm, nd, pr, pm = load_reference()
+    if "--only-r03" in sys.argv:
+        make_r03(nm, pm)
+        return
     if "--only-r02" in sys.argv:
         make_r02(nr, nm, nd, pr, pm)
         return

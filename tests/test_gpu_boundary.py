@@ -116,3 +116,74 @@ def test_two_devices_two_threads_one_process():
     assert not errs, errs
     for a, b in zip(*outs):
         assert np.array_equal(a.numpy(), b.numpy())
+
+
+def test_same_layout_other_w0_takes_the_generic_path_and_matches_the_oracle(monkeypatch):
+    """pi_GAN/modules.py:11,73: `FilmSirenNeRF(w_0=...)` is a constructor argument.  An object with the FiLM layout
+    but w_0 = 25 must NOT run the fused kernel (which hard-codes 30): it is driven through the generic path - its own
+    forward between the sampling / compositing kernels - and must match the oracle evaluated with w_0 = 25."""
+    from mirender import fields, render_core
+    from oracle import fields as ofields, parity
+
+    class FilmSiren(torch.nn.Module):                       # the reference layer's arithmetic (modules.py:22-25)
+        def __init__(self, i, o, w_0):
+            super().__init__()
+            self.w_0 = w_0
+            self.weight = torch.nn.Parameter(torch.zeros(o, i))
+            self.bias = torch.nn.Parameter(torch.zeros(o))
+
+        def forward(self, x, gamma, beta):
+            return torch.sin(self.w_0 * (gamma * torch.nn.functional.linear(x, self.weight, self.bias) + beta))
+
+    class LookAlike(torch.nn.Module):                       # modules.py:70-118
+        def __init__(self, w_0):
+            super().__init__()
+            self.film_params = None
+            self.input_layer = FilmSiren(3, 256, w_0)
+            self.hidden_layers = torch.nn.ModuleList([FilmSiren(256, 256, w_0) for _ in range(7)])
+            self.output_layer_sigma = torch.nn.Sequential(torch.nn.Linear(256, 1), torch.nn.ReLU())
+            self.hidden_layer_rgb = FilmSiren(259, 256, w_0)
+            self.output_layer_rgb = torch.nn.Sequential(torch.nn.Linear(256, 3), torch.nn.Sigmoid())
+
+        def forward(self, x):
+            fp = self.film_params
+            pos, d = x[:, :3], x[:, 3:]
+            h = self.input_layer(pos, *fp[0])
+            for i, lay in enumerate(self.hidden_layers):
+                h = lay(h, *fp[i + 1])
+            sigma = self.output_layer_sigma(h)
+            h = self.hidden_layer_rgb(torch.cat([h, d], -1), *fp[8])
+            return torch.cat([self.output_layer_rgb(h), sigma], -1)
+
+    sd = synth.state_dict("film_siren_nerf", seed=44, sharp="medium")
+    film = synth.film_params(1, seed=6)[0]
+    rays = torch.from_numpy(R.rays_from_camera(16, 16, 76.0, synth.pose_radians(1.0, 0.15, -0.1)))
+    tr = synth.t_rand(256, 8, seed=2)
+    for w_0 in (25.0, 30.0):
+        m = LookAlike(w_0).to(dev())
+        m.load_state_dict(sd)
+        m.film_params = [torch.chunk(film[i].to(dev()), 2) for i in range(9)]
+        assert fields.detect_kind(dict(m.named_parameters())) == fields.FILM_SIREN_NERF
+        pf = fields.as_packed_field(m)
+        assert (pf is None) == (w_0 != 30.0)                # 30: the fused kernel; 25: not claimed
+        monkeypatch.setattr(ofields, "W0", w_0)
+        fo = ofields.make_field("film_siren_nerf", sd, film)
+        with torch.no_grad():
+            ref = R.render_rays(rays, 0.5, 1.5, fo, fo, 8, 16, tr)
+            got = render_core.render_rays(rays.to(dev()), 0.5, 1.5, m, m, 8, 16, t_rand=tr.to(dev()))
+        case = f"FiLM look-alike w_0={w_0:g} 8+16 ({'generic path' if pf is None else 'fused kernel'})"
+        parity.gate(case, "coarse", "rgb", got[0], ref.rgb_c)
+        parity.gate(case, "coarse", "acc", got[2], ref.acc_c)
+        parity.gate(case, "coarse", "depth", got[1], ref.depth_c, tol=parity.DEPTH_TOL)
+        d = (got[3].cpu() - ref.rgb_f).abs().max(-1).values
+        frac = float((d > 1e-4).float().mean())
+        ref25 = ref if w_0 == 25.0 else ref25
+        parity.record(case=case, stage="end-to-end fine", qty="rgb", err_vs_oracle32=float(d.max()), tol=1e-4,
+                      frac_rays_over=frac, active="distribution", passed=frac <= 0.03)
+        assert frac <= 0.03, (w_0, float(d.max()), frac)
+    # and the two really differ: had w_0 = 25 been routed to the fused kernel, the coarse image would be the w_0 = 30 one
+    monkeypatch.setattr(ofields, "W0", 30.0)
+    fo30 = ofields.make_field("film_siren_nerf", sd, film)
+    with torch.no_grad():
+        ref30 = R.render_rays(rays, 0.5, 1.5, fo30, fo30, 8, 16, tr)
+    assert float((ref30.rgb_c - ref25.rgb_c).abs().max()) > 1e-2

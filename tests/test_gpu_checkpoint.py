@@ -71,16 +71,25 @@ def test_reference_layout_state_dict_into_fused_module(kind, tmp_path):
     here from nn.Linear pieces with those names, saved as the reference saves, loaded weights-only, rendered by both
     the look-alike (recognised by layout) and the fused module built from the file."""
     from mirender import checkpoint, fields, render_core
-    L = torch.nn.Linear
     k_in, k_skip, k_dir = (60, 316, 280) if kind == "nerf" else (3, 259, 259)
+
+    class Dense(torch.nn.Linear):                       # carries its activation's name like nerf/nerf.py:15
+        def __init__(self, i, o, activation="linear"):
+            super().__init__(i, o)
+            self.activation_name = activation
+
+    class Siren(torch.nn.Linear):                       # nerf/nerf.py:97-117: the class IS the activation
+        pass
+
+    H = (lambda i, o: Dense(i, o, "relu")) if kind == "nerf" else Siren
 
     class RefLike(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.layers_pos = torch.nn.ModuleList([L(k_in, 256)] + [L(256, 256) for _ in range(4)] + [L(k_skip, 256), L(256, 256), L(256, 256)])
-            self.layers_dir = torch.nn.ModuleList([L(256, 256), L(k_dir, 128)])
-            self.output_layer_sigma = L(256, 1)
-            self.output_layer_rgb = L(128, 3)
+            self.layers_pos = torch.nn.ModuleList([H(k_in, 256)] + [H(256, 256) for _ in range(4)] + [H(k_skip, 256), H(256, 256), H(256, 256)])
+            self.layers_dir = torch.nn.ModuleList([Dense(256, 256), H(k_dir, 128)])
+            self.output_layer_sigma = Dense(256, 1, "relu")
+            self.output_layer_rgb = Dense(128, 3, "sigmoid")
 
     sd = synth.state_dict(kind, seed=72, sharp="medium", bias_jitter=0.05)
     ref_like = RefLike()

@@ -305,6 +305,40 @@ def test_partial_save_and_recompute_give_the_same_gradients(kind, monkeypatch):
         assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(a.abs().max()))
 
 
+def test_out_of_memory_in_backward_falls_back_to_recompute(monkeypatch):
+    """the forward's save budget is an estimate of what the allocator can still give; if backward cannot
+    allocate a range's gradient rows next to the kept layer inputs, it gives the remaining kept inputs back and
+    recomputes them (same gradients bit for bit) instead of failing in the middle of the pass."""
+    from mirender import autograd, fields, render_core
+    m = fields.field_from_state_dict(synth.state_dict("film_siren_nerf", seed=34), dev())
+    film = synth.film_params(4, seed=3).to(dev()).requires_grad_(True)
+    n, nc, nf = 4 * 96, 8, 16
+    rays = torch.from_numpy(R.rays_from_camera(24, 16, 33.3, synth.pose_degrees(1.0, 20.0, -30.0))[:n]).to(dev())
+    tr = synth.t_rand(n, nc, seed=6).to(dev())
+    monkeypatch.setattr(autograd, "_max_points_per_chunk", lambda pf: 96 * (nc + nf))      # 4 ranges, all kept
+    results, real, calls = [], autograd._guarded, {"n": 0, "raised": 0}
+
+    def flaky(nfloats, d):
+        calls["n"] += 1
+        if calls["armed"] and calls["n"] == 3:               # the second range's first allocation
+            calls["raised"] += 1
+            raise torch.cuda.OutOfMemoryError("injected by the test")
+        return real(nfloats, d)
+    monkeypatch.setattr(autograd, "_guarded", flaky)
+    for armed in (False, True):
+        calls.update(n=0, armed=False)
+        for p in m.parameters():
+            p.grad = None
+        film.grad = None
+        out = render_core.render_rays(rays, 0.5, 1.5, m, m, nc, nf, t_rand=tr, film=film)
+        calls.update(n=0, armed=armed)                       # count (and fail) backward's allocations only
+        out[3].square().mean().backward()
+        results.append([p.grad.clone() for p in m.parameters()] + [film.grad.clone()])
+    assert calls["raised"] == 1
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 def test_film_parameter_optimisation_through_generator_render():
     """pi_GAN/synthesis.py:83-107: GAN inversion optimises ONE image's FiLM parameters directly (a [9,512] leaf,
     Adam lr 1e-4 there) through `generator.set_film_params(film_params); generator.render(0, 0)` and a second render at

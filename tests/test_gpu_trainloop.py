@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from oracle import synth, train_ref as T  # noqa: E402
+from oracle import render_ref as R, synth, train_ref as T  # noqa: E402
 
 
 def dev():
@@ -17,10 +17,10 @@ def dev():
 
 @pytest.fixture(scope="module")
 def mi():
-    from mirender import _lib, fields, render_core, train
+    from mirender import _lib, fields, ops, render_core, train
     assert torch.cuda.is_available(), "gpu tests need a ROCm device"
     _lib.load()
-    return type("MI", (), {"fields": fields, "train": train, "render_core": render_core, "lib": _lib})
+    return type("MI", (), {"fields": fields, "train": train, "render_core": render_core, "lib": _lib, "ops": ops})
 
 
 def test_loss_golden_f7(mi, golden):
@@ -238,3 +238,56 @@ def test_ray_bank_float64_focal_and_reference_reshuffle_quirk(mi):
     again = [quirk.batch(50)[0].clone() for _ in range(3)]
     for a, b in zip(first, again):
         assert torch.equal(a, b)
+
+
+def test_fused_adam_step_between_forward_and_backward_raises(mi):
+    """FusedAdam rewrites the parameters from a raw kernel, so torch's version counters do not move; the
+    field's own epoch does, and a forward still waiting for its backward must see it (mixed-weights gradients would be
+    silent otherwise).  The streams themselves stay valid: the next forward needs no repack."""
+    m = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=63, sharp="medium", bias_jitter=0.05), dev())
+    pf = mi.fields.as_packed_field(m)
+    rays = torch.from_numpy(R.rays_from_camera(12, 12, 16.0, synth.pose_degrees(4.0, 5.0, -30.0))).to(dev())
+    tr = synth.t_rand(144, 8, seed=1).to(dev())
+    opt = mi.train.FusedAdam(m, lr=1e-3)
+    out = mi.render_core.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    out[3].square().mean().backward()                     # gradients for the step
+    stale = mi.render_core.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    stamp = pf._versions
+    opt.step()
+    assert pf._versions != stamp and pf._versions == pf.versions()        # re-stamped: still current, no repack due
+    with pytest.raises(RuntimeError, match="modified in place"):
+        stale[3].square().mean().backward()
+    packed_before = pf.packed.clone()
+    fresh = mi.render_core.render_rays(rays, 2.0, 6.0, m, m, 8, 8, t_rand=tr)
+    assert torch.equal(pf.packed, packed_before)           # the forward after the step used the patched stream as is
+    fresh[3].square().mean().backward()                    # and its own backward is fine
+
+
+def test_adam_step_rejects_tensors_that_are_not_weight_bias_pairs(mi):
+    """mi_adam_step takes each weight's row length from the bias that follows it: a zero-sized or non-dividing bias is
+    an argument error (MI_EINVAL), not a division fault."""
+    import ctypes
+    m = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=64), dev())
+    pf = mi.fields.as_packed_field(m)
+    ps = list(pf.params)
+    z = [torch.zeros_like(p) for p in ps]
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[x.data_ptr() for x in ts])  # noqa: E731
+    kinds = (ctypes.c_int * 1)(pf.kind)
+    for bad_index, bad_value in ((1, 0), (1, 7)):
+        numel = [p.numel() for p in ps]
+        numel[bad_index] = bad_value
+        rc = mi.lib.load().mi_adam_step(1, kinds, arr(ps), arr(z), arr(z), arr(z), (ctypes.c_int64 * len(ps))(*numel),
+                                        -1e-3, 0.1, 0.999, 0.001, 1e-8, 1.0, arr([pf.refresh()]),
+                                        (ctypes.c_void_p * 1)(None), mi.lib.stream_ptr(dev()))
+        assert rc == -1 and b"weight" in mi.lib.load().mi_last_error()
+
+
+def test_workspace_release_accepts_any_spelling_of_the_device(mi):
+    m = mi.fields.field_from_state_dict(synth.state_dict("tiny_nerf", seed=65), dev())
+    rays = torch.from_numpy(R.rays_from_camera(8, 8, 11.0, synth.pose_degrees(4.0, 5.0, -30.0))).to(dev())
+    for spelling in ("cuda", "cuda:0", torch.device("cuda"), torch.device("cuda", 0), 0, None):
+        with torch.no_grad():
+            mi.render_core.render_rays(rays, 2.0, 6.0, m, m, 8, 8, seed=1)
+        assert any(k[0] == "cuda:0" for k in mi.ops._Workspace.bufs)
+        mi.ops._Workspace.release(spelling)
+        assert not any(k[0] == "cuda:0" for k in mi.ops._Workspace.bufs), spelling

@@ -165,3 +165,69 @@ def test_bench_spawns_its_own_ranks(monkeypatch):
     assert e.value.code == 7
     assert "--nproc-per-node=2" in seen["cmd"] and seen["cmd"][-4:] == ["--gpus", "2", "--steps", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _rebuild_from_attrs(kind_name, layers):
+    """A torch module tree whose layer objects carry exactly what tests/golden/ref_layer_attrs.json recorded from the
+    reference's own classes (class name, activation_name, w_0, the module after a Linear in its Sequential)."""
+    from mirender import fields
+    kind = {v: k for k, v in fields.KIND_NAMES.items()}[kind_name]
+    root = torch.nn.Module()
+    for key, (o, i) in fields.SPECS[kind]:
+        rec = layers[key]
+        if rec["class"] == "Linear":
+            leaf = torch.nn.Linear(i, o)
+        else:
+            leaf = type(rec["class"], (torch.nn.Linear,), {})(i, o)
+        for attr in ("activation_name", "w_0"):
+            if attr in rec:
+                setattr(leaf, attr, rec[attr])
+        parts = key.split(".")
+        if len(parts) == 1:
+            root.add_module(parts[0], leaf)
+        elif "next_in_sequential" in rec:
+            root.add_module(parts[0], torch.nn.Sequential(leaf, getattr(torch.nn, rec["next_in_sequential"])()))
+        else:
+            if not hasattr(root, parts[0]):
+                root.add_module(parts[0], torch.nn.ModuleList())
+            getattr(root, parts[0]).append(leaf)
+    return kind, root
+
+
+def test_same_layout_other_arithmetic_is_not_claimed():
+    """a recognised layout is not enough - the kernels hard-code each layer's activation and w_0 = 30.
+    The reference's own classes (their layer objects' self-description dumped into ref_layer_attrs.json by importing
+    them) must pass; FilmSirenNeRF(w_0=25) (pi_GAN/modules.py:73), a Dense stack with another activation name
+    (nerf/nerf.py:15-16) and a bare nn.Linear stack must fall to the generic path (as_packed_field -> None)."""
+    import json
+    import os
+    from mirender import fields
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_layer_attrs.json")) as f:
+        ref = json.load(f)
+    for name, rec in ref.items():
+        kind, m = _rebuild_from_attrs(rec["kind"], rec["layers"])
+        assert fields.detect_kind(dict(m.named_parameters())) == kind, name
+        why = fields.hyper_mismatch(m, kind)
+        if "w_0=25" in name:
+            assert why is not None and "w_0" in why, (name, why)
+            assert fields.as_packed_field(m) is None           # generic path; no device needed to decide that
+        else:
+            assert why is None, (name, why)
+    # NeRF layout, one hidden Dense switched to tanh; SirenNeRF layout whose sin layers are Dense('relu')
+    layers = json.loads(json.dumps(ref["nerf.NeRF"]["layers"]))
+    layers["layers_pos.3"]["activation_name"] = "tanh"
+    kind, m = _rebuild_from_attrs("nerf", layers)
+    assert "tanh" in fields.hyper_mismatch(m, kind) and fields.as_packed_field(m) is None
+    layers = json.loads(json.dumps(ref["nerf.SirenNeRF"]["layers"]))
+    for k in layers:
+        if layers[k]["class"] == "Siren":
+            layers[k] = {"class": "Dense", "activation_name": "relu"}
+    kind, m = _rebuild_from_attrs("siren_nerf", layers)
+    assert fields.hyper_mismatch(m, kind) is not None and fields.as_packed_field(m) is None
+    # a stack of bare nn.Linear says nothing about its activations: not claimed either
+    layers = {k: {"class": "Linear"} for k in ref["nerf.NeRF"]["layers"]}
+    kind, m = _rebuild_from_attrs("nerf", layers)
+    assert fields.hyper_mismatch(m, kind) is not None
+    # our own modules name their activations and are claimed
+    for cls in (fields.NeRF, fields.TinyNeRF, fields.SirenNeRF, fields.FilmSirenNeRF, fields.FilmSirenNeRFNoDir):
+        assert fields.hyper_mismatch(cls(), cls.KIND) is None, cls
