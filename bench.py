@@ -20,7 +20,8 @@ Extra objects in the line:
                 the same workload, rank 0, N=1 only; with it `psnr_vs_ref`: held-out-view PSNR of a TinyNeRF fitted
                 to a synthetic teacher scene by the HIP path and by the reference loop on the CPU (oracle/fit_ref.py)
   train         N=1 only: the secondary training workloads (nerf 1024-ray step x40, pi_GAN C4 step x3)
-  collective    N>1: ranks seen by torch.distributed, per-rank mean MLP launch time, all-gather time per frame
+  collective    N>1 (or --force-collective): ranks seen by torch.distributed, per-rank mean MLP launch time,
+                all-gather time per frame
 """
 import argparse
 import json
@@ -34,6 +35,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "msra-practice-project_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+# Every rank process - whether torch.distributed.run was started by the driver or by this script's own spawn below -
+# gets the same HSA setting before anything initialises the GPU: the hosts of this pool support dmabuf IPC only, and
+# with the legacy IPC mode RCCL's peer-to-peer setup (and any device-tensor sharing across processes) fails with
+# `hipIpcGetMemHandle: invalid argument`.  The image exports it already; setdefault keeps an explicit override.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -138,6 +145,17 @@ def cpu_baseline(sample_rays=8192):
                       f"NeRF coarse+fine, torch CPU no_grad, {dt:.1f} s"}
 
 
+def newest_profile(suffix: str):
+    """profiles/rNN_<suffix> of the latest round that has one (the PMC summaries tools/profile_round.sh commits)."""
+    import glob
+    import re
+    found = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")):
+        m = re.match(r"r(\d\d)_", os.path.basename(path))
+        found.append((int(m.group(1)), path))
+    return max(found)[1] if found else None
+
+
 def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=None):
     """Secondary workloads (not the headline line): one training step per `step`, data-parallel over ranks
     (each rank its own batch = weak scaling) with one flat RCCL all-reduce of the renderer gradients.
@@ -218,59 +236,76 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
     # HBM bytes per step: not measurable from inside the process; from the committed rocprofv3 PMC passes of this same
     # workload (profiles/r02_pmc_<workload>.json: WRITE_SIZE + 2 x FETCH_SIZE summed over every kernel of the two traced
     # steps, tools/summarise_pmc.py).  null if absent.
-    traffic = None
+    traffic, pmc_path = None, newest_profile(f"pmc_{workload}.json")
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", f"r02_pmc_{workload}.json")))
+        pmc = json.load(open(pmc_path))
         traffic = sum(k["hbm_bytes_2xFETCH_plus_WRITE"] for k in pmc["kernels"].values()) / 2
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, TypeError):
         pass
+    pmc_name = os.path.basename(pmc_path) if pmc_path else None
+    extra = {}
+    if workload == "nerf_train":
+        # the reference's 1024-ray batch split over 8 GPUs would be 128 rays each - too small to mean
+        # anything; here every rank keeps its own 1024 rays (weak scaling), so the global batch grows with N.  Say so.
+        extra["nerf_train_global_batch"] = world * rays_per_step
     return {
         "metric": "rays/sec (training step)", "value": world * rays_per_step * steps / elapsed, "unit": "rays/s",
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step,
+        "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step, **extra,
                    "parallelism": f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU"},
+        "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
+                       "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
+                       "grad_allreduce_bytes": int(sum(p.numel() for p in params) * 4),
+                       "note": "one flat all_reduce of the renderer gradients per step (mirender.dist.allreduce_grads)"},
         "roofline": {"bound": "mfma", "kernel": "whole training step (forward, backward chain, dW GEMMs)",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
-                     "traffic_unit": f"HBM bytes per step (PMC, profiles/r02_pmc_{workload}.json)",
+                     "traffic_unit": f"HBM bytes per step (PMC, profiles/{pmc_name})",
                      "note": "algorithmic FLOPs = 2 x MACs x (1 per no-grad pass + 3 per trained pass), SURVEY.md 8d"},
     }
 
 
 def psnr_vs_ref(dev):
-    """The metric's "PSNR vs ref" clause on a trained result: a TinyNeRF pair fitted to the synthetic teacher scene of
-    oracle/fit_ref.py (60 Adam steps of 256 rays, 24x24 views, 16+16 samples) by the HIP path and by the reference
-    loop on the CPU - same initial weights, batches and jitter; held-out-view PSNR of both.  Part of the CPU-baseline
-    leg (the only place bench.py touches oracle/)."""
+    """The metric's "PSNR vs ref" clause on trained results: student pairs fitted to the synthetic teacher scene of
+    oracle/fit_ref.py (24x24 views, 16+16 samples, the loop of nerf/train_nerf.py:124-176) by the HIP path and by the
+    reference loop on the CPU - same initial weights, rays and jitter; held-out-view PSNR of both.  TinyNeRF (PE + ReLU):
+    60 Adam steps of 256 rays at 5e-4; SirenNeRF (the sin family): 15 Adam steps over all 3 456 rays at 1e-5 - regimes
+    in which the CPU loop itself is reproducible under a 1e-6 perturbation of its initial weights to 1e-3 / 5e-5 in the losses (tests/test_gpu_psnr.py gates them hard).
+    Part of the CPU-baseline leg (the only place bench.py touches oracle/)."""
     from mirender import fields, render_core
     from oracle import fit_ref, render_ref as R
-    steps, batch = 60, 256
-    scene = fit_ref.Scene()
-    cpu_losses, cpu_psnr, _ = fit_ref.fit_cpu(scene, steps, batch)
-    cm, fm = fields.TinyNeRF().to(dev), fields.TinyNeRF().to(dev)
-    cm.load_state_dict(scene.student_init[0])
-    fm.load_state_dict(scene.student_init[1])
-    opt = torch.optim.Adam(list(cm.parameters()) + list(fm.parameters()), lr=5e-4, betas=(0.9, 0.999))
-    loss = None
-    for step in range(steps):
-        rays, rgb, tr = scene.batch(step, batch)
-        rgb = rgb.to(dev)
-        out = render_core.render_rays(rays.to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf, t_rand=tr.to(dev))
-        loss = torch.mean((out[3] - rgb) ** 2) + torch.mean((out[0] - rgb) ** 2)
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        for g in opt.param_groups:
-            g["lr"] = fit_ref.lr_at(step + 1)
-    with torch.no_grad():
-        held = render_core.render_rays(scene.rays[-1].to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf,
-                                       t_rand=scene.heldout_jitter().to(dev))
-    hip_psnr = R.psnr(held[3].cpu().numpy(), scene.images[-1].numpy())
-    return {"hip_db": hip_psnr, "cpu_reference_loop_db": cpu_psnr, "diff_db": hip_psnr - cpu_psnr,
-            "final_loss_hip": float(loss), "final_loss_cpu": cpu_losses[-1],
-            "scene": f"teacher tiny_nerf field, six 24x24 training views + 1 held out, 16+16 samples, {steps} Adam steps "
-                     f"of {batch} rays (nerf/train_nerf.py:124-176 loop), PSNR of the held-out view against the teacher image"}
+    out = {}
+    for student, lr0, batch, steps in (("tiny_nerf", 5e-4, 256, 60), ("siren_nerf", 1e-5, 0, 15)):
+        scene = fit_ref.Scene(student=student)
+        cpu_losses, cpu_psnr, _ = fit_ref.fit_cpu(scene, steps, batch, lr0=lr0)
+        cm, fm = fields.field_from_state_dict(scene.student_init[0], dev), fields.field_from_state_dict(scene.student_init[1], dev)
+        opt = fit_ref.make_optimizer(list(cm.parameters()) + list(fm.parameters()), "adam", lr0)
+        loss, worst = None, 0.0
+        for step in range(steps):
+            rays, rgb, tr = scene.batch(step, batch)
+            rgb = rgb.to(dev)
+            o = render_core.render_rays(rays.to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf, t_rand=tr.to(dev))
+            loss = torch.mean((o[3] - rgb) ** 2) + torch.mean((o[0] - rgb) ** 2)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            for g in opt.param_groups:
+                g["lr"] = fit_ref.lr_at(step + 1, lr0)
+            worst = max(worst, abs(float(loss) - cpu_losses[step]) / cpu_losses[step])
+        with torch.no_grad():
+            held = render_core.render_rays(scene.rays[-1].to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf,
+                                           t_rand=scene.heldout_jitter().to(dev))
+        hip_psnr = R.psnr(held[3].cpu().numpy(), scene.images[-1].numpy())
+        out[student] = {"hip_db": hip_psnr, "cpu_reference_loop_db": cpu_psnr, "diff_db": hip_psnr - cpu_psnr,
+                        "final_loss_hip": float(loss), "final_loss_cpu": cpu_losses[-1], "max_rel_loss_diff": worst,
+                        "regime": f"{steps} Adam steps (lr {lr0:g}) of {batch or 'all 3456'} rays"}
+    # the headline pair stays at the top level (round-2 readers), the per-family results under "families"
+    top = dict(out["tiny_nerf"])
+    top["families"] = out
+    top["scene"] = ("teacher tiny_nerf field, six 24x24 training views + 1 held out, 16+16 samples (nerf/train_nerf.py:124-176 "
+                    "loop), PSNR of the held-out view against the teacher image")
+    return top
 
 
 def spawn_command(argv, n_gpus: int, port: int):
@@ -298,6 +333,9 @@ def main():
                     help="skip the secondary 64-sample frame (profiling runs: keeps every nerf_fwd_kernel launch in the "
                          "trace one of the timed step's two launches, so rocprofv3's average matches roofline.avg_launch_ms)")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary training workloads folded into the N=1 line")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: initialise a one-rank nccl (RCCL) group and issue the frame's all-gather / the gradient "
+                         "all-reduce anyway (mirender.dist.FORCE_COLLECTIVE), so the collective code runs on a one-GPU box")
     ap.add_argument("--workload", default="c3", choices=["c3", "c4", "c5", "nerf_train"],
                     help="c3 (default, the headline line) | c4 | c5 | nerf_train (secondary training workloads)")
     args = ap.parse_args()
@@ -325,11 +363,17 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif args.force_collective:
+        from mirender import dist as mdist
+        for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1").items():
+            os.environ.setdefault(k, v)
+        dist.init_process_group("nccl", device_id=dev)
+        mdist.FORCE_COLLECTIVE = True
     if args.workload != "c3":
         line = train_workload(args, world, rank, dev)
         if rank == 0:
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
         return
 
@@ -382,12 +426,12 @@ def main():
     # passes of this same command (profiles/r01_pmc_nerf_fwd.json: WRITE_SIZE + 2 x FETCH_SIZE per the gfx950
     # correction of MI355X_MICROARCH.md, per point) scaled to the mean points per launch.  null if absent.
     traffic = None
+    pmc_path = newest_profile("pmc_nerf_fwd.json")
+    pmc_name = os.path.basename(pmc_path) if pmc_path else None
     try:
-        pmc_name = next(n for n in ("r02_pmc_nerf_fwd.json", "r01_pmc_nerf_fwd.json")
-                        if os.path.exists(os.path.join(ROOT, "profiles", n)))
-        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+        pmc = json.load(open(pmc_path))
         traffic = pmc["derived_fine_launch"]["hbm_bytes_per_point_upper"] * mean_flops / flops_pt
-    except (OSError, KeyError, ValueError, StopIteration):
+    except (OSError, KeyError, ValueError, TypeError):
         pmc_name = None
     roofline = {"bound": "mfma", "kernel": "nerf_fwd_kernel", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
@@ -413,7 +457,7 @@ def main():
     # what the collective cost and who took part: ranks as torch.distributed sees them, every rank's mean MLP launch
     # time (the shards are equal, so these should be too) and its mean all-gather time per frame
     collective = None
-    if world > 1:
+    if dist.is_initialized():
         gather_ms = [a.elapsed_time(b) for a, b in gather_events]
         mine = torch.tensor([mean_ms, sum(gather_ms) / max(1, len(gather_ms))], dtype=torch.float64, device=dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
@@ -437,6 +481,7 @@ def main():
         for wl, (k, w) in (("nerf_train", (40, 8)), ("c4", (3, 1))):
             r = train_workload(args, world, rank, dev, workload=wl, steps=k, warmup=w)
             train[wl] = {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "n_ranks_seen": r["collective"]["n_ranks_seen"],
                          "tflops": r["roofline"]["achieved"], "frac_of_fp32_mfma_peak": r["roofline"]["frac"],
                          "workload": r["config"]["workload"]}
             torch.cuda.empty_cache()
@@ -468,9 +513,26 @@ def main():
             line["gpu_over_cpu"] = rays_per_s / line["cpu_baseline"]["value"]
             line["psnr_vs_ref"] = psnr_vs_ref(dev)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
+def run():
+    """main(), with a rank's failure made visible: its traceback goes to stderr tagged with the rank (torch.distributed.run
+    and this script's own spawn both pass the ranks' stderr through) and the process exits non-zero, which makes the
+    launcher stop the other ranks and return non-zero itself - no JSON line, no zero exit code after a failed rank."""
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:      # noqa: BLE001
+        import traceback
+        rank = os.environ.get("RANK", "0")
+        sys.stderr.write(f"[bench.py rank {rank}] FAILED:\n" + "".join(f"[bench.py rank {rank}] {ln}" for ln in
+                                                                       traceback.format_exc().splitlines(True)))
+        sys.stderr.flush()
+        sys.exit(1)
+
+
 if __name__ == "__main__":
-    main()
+    run()

@@ -334,8 +334,8 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
     static_for<(KB + 1) / 2>(stage);
 }
 
-// FiLM's gamma * A + beta (pi_GAN/modules.py:24): a rounded product, then a rounded sum, two elements at a time
-__device__ __forceinline__ f32x2 film_affine(f32x2 g, f32x2 v, f32x2 b) {
+// FiLM's gamma * A + beta (pi_GAN/modules.py:24): a rounded product, then a rounded sum, four elements at a time
+__device__ __forceinline__ f32x4 film_affine(f32x4 g, f32x4 v, f32x4 b) {
 #pragma clang fp contract(off)
     return g * v + b;
 }
@@ -403,29 +403,24 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
             }
         }
         const f32x4 bias = bias_q[idx & 1];
-        f32x4 xo;
-#pragma unroll
-        for (int q = 0; q < 4; q += 2) {
-            f32x2 v = f32x2{acc[m][4 * rg + q], acc[m][4 * rg + q + 1]} + f32x2{bias[q], bias[q + 1]};
-            f32x2 o;
-            if constexpr (ACT == ACT_RELU) o = f32x2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)};
-            else if constexpr (ACT == ACT_LINEAR) o = v;
-            else {
-                if constexpr (ACT == ACT_FILM) {
-                    const f32x4 g = g_q[idx & 1], bb = bb_q[idx & 1];
-                    v = film_affine(f32x2{g[q], g[q + 1]}, v, f32x2{bb[q], bb[q + 1]});
-                }
-                if constexpr (SAVE) {
-                    const SinSaved2 sc = hw_sin30_saved_x2(v);
-                    o = sc.s;
-                    xo[q] = sc.saved.x; xo[q + 1] = sc.saved.y;
-                } else {
-                    o = hw_sin30_x2(v);
-                }
+        // the whole quarter as ONE four-wide value: every step is two independent packed instructions back to back, so no
+        // dependent packed op waits a state on its predecessor (mi_math.h:hw_turns30_x4)
+        f32x4 v = f32x4{acc[m][4 * rg + 0], acc[m][4 * rg + 1], acc[m][4 * rg + 2], acc[m][4 * rg + 3]} + bias;
+        f32x4 o, xo;
+        if constexpr (ACT == ACT_RELU) { o = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; xo = o; }
+        else if constexpr (ACT == ACT_LINEAR) { o = v; xo = o; }
+        else {
+            if constexpr (ACT == ACT_FILM) v = film_affine(g_q[idx & 1], v, bb_q[idx & 1]);
+            if constexpr (SAVE) {
+                const SinSaved4 sc = hw_sin30_saved_x4(v);
+                o = sc.s;
+                xo = sc.saved;
+            } else {
+                o = hw_sin30_x4(v);
+                xo = o;
             }
-            X[m][4 * rg + q] = o.x; X[m][4 * rg + q + 1] = o.y;
-            if constexpr (!kSinAct) { xo[q] = o.x; xo[q + 1] = o.y; }
         }
+        X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
         if constexpr (SAVE && (kSinAct || !DEFER_X)) {
             // float4 index m*8 + rg*2 inside the row (h folded into the row pointer)
             // NOT guarded by sv.valid: lanes past the end of a partial tile are clamped to its last point, compute

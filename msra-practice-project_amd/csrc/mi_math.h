@@ -42,9 +42,29 @@ __device__ __forceinline__ float hw_turns(float t) {
     const float lo = fmaf(t, c_lo, fmaf(t, c_hi, -hi));
     return (hi - rintf(hi)) + lo;
 }
+// MI_SIN_VARIANT (diagnostic builds, tools/diag_build.sh sin<k>; the product is built with the default):
+//   0  t = fl(30 u); n = rndne(fl(t c_hi)); r = fma(t, c_lo, fma(t, c_hi, -n))      5 VALU + v_sin   2.5e-7 / 4.9e-8
+//   1  t = fl(30 u); n = rndne(fl(t c_hi)); r = fma(t, c_hi, -n)   (no c_lo term)   4 VALU + v_sin
+//   2  t = fl(30 u); r = fract(fl(t c_hi))                                           3 VALU + v_sin
+//   3  r = fract(fl(u K)), K = fl(30 / 2 pi)   (the product 30 u is never rounded)   2 VALU + v_sin
+// (errors against sin(fl(30 u)) over the probe's |u| < 40: tools/probes/sin_variants.hip; what they cost in parity and
+// buy in MFMA-busy time: DESIGN.md 4.1)
+#ifndef MI_SIN_VARIANT
+#define MI_SIN_VARIANT 0
+#endif
 __device__ __forceinline__ float hw_turns30(float u) {
 #pragma clang fp contract(off)
+#if MI_SIN_VARIANT == 0
     return hw_turns_fast(30.f * u);
+#elif MI_SIN_VARIANT == 1
+    const float c_hi = 0.15915494309189535f;
+    const float t = 30.f * u;
+    return fmaf(t, c_hi, -rintf(t * c_hi));
+#elif MI_SIN_VARIANT == 2
+    return __builtin_amdgcn_fractf((30.f * u) * 0.15915494309189535f);
+#else
+    return __builtin_amdgcn_fractf(u * 4.774648292756860f);                    // 30 / (2 pi)
+#endif
 }
 #if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1     // diagnostic builds only (tools/diag_build.sh): no activation work at all
 __device__ __forceinline__ float hw_sin30(float u) { return u; }
@@ -73,8 +93,23 @@ __device__ __forceinline__ f32x2 hw_turns_x2(f32x2 t) {
 }
 __device__ __forceinline__ f32x2 hw_turns30_x2(f32x2 u) {
 #pragma clang fp contract(off)
+#if MI_SIN_VARIANT == 0
     const f32x2 w0 = {30.f, 30.f};
     return hw_turns_x2(u * w0);
+#elif MI_SIN_VARIANT == 1
+    const f32x2 w0 = {30.f, 30.f}, c_hi = {0.15915494309189535f, 0.15915494309189535f};
+    const f32x2 t = u * w0, hi = t * c_hi;
+    const f32x2 n = {rintf(hi.x), rintf(hi.y)};
+    return __builtin_elementwise_fma(t, c_hi, -n);
+#elif MI_SIN_VARIANT == 2
+    const f32x2 w0 = {30.f, 30.f}, c_hi = {0.15915494309189535f, 0.15915494309189535f};
+    const f32x2 hi = (u * w0) * c_hi;
+    return f32x2{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y)};
+#else
+    const f32x2 k = {4.774648292756860f, 4.774648292756860f};
+    const f32x2 hi = u * k;
+    return f32x2{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y)};
+#endif
 }
 __device__ __forceinline__ f32x2 hw_sin30_x2(f32x2 u) {
     const f32x2 r = hw_turns30_x2(u);
@@ -116,6 +151,60 @@ __device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {
     o.s = sn;
     o.saved.x = cos_sign_into(sn.x, r.x);
     o.saved.y = cos_sign_into(sn.y, r.y);
+    return o;
+}
+
+// Four elements (one epilogue quarter) at a time.  A dependent chain of packed fp32 ops costs a wait state between any
+// two of them (the ISA listing of the two-wide form shows an `s_nop 0` after every v_pk_mul / v_pk_fma: an issue slot
+// each, on a wave whose every issue slot between two MFMAs is paid in full); written four wide, each step is TWO
+// independent packed instructions back to back and the wait states disappear: 4.5 instead of 6.5-7 issue slots per
+// element for the default reduction.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4m hw_turns30_x4(f32x4m u) {
+#pragma clang fp contract(off)
+    const float c_hi = 0.15915494309189535f;
+#if MI_SIN_VARIANT == 0
+    const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
+    const f32x4m t = u * 30.f, hi = t * c_hi;
+    const f32x4m n = {rintf(hi.x), rintf(hi.y), rintf(hi.z), rintf(hi.w)};
+    const f32x4m k_hi = {c_hi, c_hi, c_hi, c_hi}, k_lo = {c_lo, c_lo, c_lo, c_lo};
+    return __builtin_elementwise_fma(t, k_lo, __builtin_elementwise_fma(t, k_hi, -n));
+#elif MI_SIN_VARIANT == 1
+    const f32x4m t = u * 30.f, hi = t * c_hi;
+    const f32x4m n = {rintf(hi.x), rintf(hi.y), rintf(hi.z), rintf(hi.w)};
+    const f32x4m k_hi = {c_hi, c_hi, c_hi, c_hi};
+    return __builtin_elementwise_fma(t, k_hi, -n);
+#elif MI_SIN_VARIANT == 2
+    const f32x4m hi = (u * 30.f) * c_hi;
+    return f32x4m{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y), __builtin_amdgcn_fractf(hi.z), __builtin_amdgcn_fractf(hi.w)};
+#else
+    const f32x4m hi = u * 4.774648292756860f;
+    return f32x4m{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y), __builtin_amdgcn_fractf(hi.z), __builtin_amdgcn_fractf(hi.w)};
+#endif
+}
+__device__ __forceinline__ f32x4m hw_sin4(f32x4m r) {
+#if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 3
+    return r;
+#else
+    return f32x4m{__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y), __builtin_amdgcn_sinf(r.z), __builtin_amdgcn_sinf(r.w)};
+#endif
+}
+__device__ __forceinline__ f32x4m hw_sin30_x4(f32x4m u) {
+#if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1
+    return u;
+#elif defined(MI_DIAG_SIN) && MI_DIAG_SIN == 2
+    return hw_sin4(u);
+#else
+    return hw_sin4(hw_turns30_x4(u));
+#endif
+}
+struct SinSaved4 { f32x4m s, saved; };
+__device__ __forceinline__ SinSaved4 hw_sin30_saved_x4(f32x4m u) {
+    const f32x4m r = hw_turns30_x4(u);
+    const f32x4m sn = hw_sin4(r);
+    SinSaved4 o;
+    o.s = sn;
+    o.saved = f32x4m{cos_sign_into(sn.x, r.x), cos_sign_into(sn.y, r.y), cos_sign_into(sn.z, r.z), cos_sign_into(sn.w, r.w)};
     return o;
 }
 

@@ -9,8 +9,21 @@ device from (W, H, focal, c2w) so nothing is scattered, and ONE all-gather of pa
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+# With one rank there is nothing to exchange and the collectives are skipped - unless this switch is on (environment
+# MI_FORCE_COLLECTIVE=1, `bench.py --force-collective`, tests/test_gpu_rccl.py): then a one-rank group still issues
+# every collective, so the RCCL calls of this module execute (and are checked bit for bit against the ungrouped
+# result) on a one-GPU box, before an 8-GPU node ever sees them.
+FORCE_COLLECTIVE = os.environ.get("MI_FORCE_COLLECTIVE") == "1"
+
+
+def _exchange(group=None) -> bool:
+    """True when a collective has to be issued: a group exists and it has peers (or FORCE_COLLECTIVE is on)."""
+    return dist.is_initialized() and (dist.get_world_size(group) > 1 or FORCE_COLLECTIVE)
 
 
 def shard_range(total: int, rank: int, world: int):
@@ -23,10 +36,9 @@ def shard_range(total: int, rank: int, world: int):
 def all_gather_rays(local: torch.Tensor, total: int, group=None) -> torch.Tensor:
     """local [n_local, C] (this rank's shard_range rows) -> [total, C] on every rank, one collective.
     Shards are padded to the largest shard so a single all_gather_into_tensor moves everything."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    if world == 1:
+    if not _exchange(group):
         return local
+    world = dist.get_world_size(group)
     width = local.shape[1]
     longest = -(-total // world)
     send = local
@@ -55,14 +67,14 @@ def render_image_sharded(render_shard, width: int, height: int, group=None, timi
     a, b = shard_range(total, rank, world)
     rgb, depth, acc = render_shard(a, b - a)
     packed = torch.cat([rgb.reshape(-1, 3), depth.reshape(-1, 1), acc.reshape(-1, 1)], 1)
-    if world > 1 and timing is not None and packed.is_cuda:
+    if _exchange(group) and timing is not None and packed.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
         full = all_gather_rays(packed, total, group)
         ev[1].record()
         timing.append(ev)
     else:
-        full = all_gather_rays(packed, total, group) if world > 1 else packed
+        full = all_gather_rays(packed, total, group) if _exchange(group) else packed
     return (full[:, :3].reshape(height, width, 3), full[:, 3:4].reshape(height, width, 1),
             full[:, 4:5].reshape(height, width, 1))
 
@@ -83,7 +95,7 @@ def render_image_dist(width, height, focal, pose, near, far, coarse_model, fine_
 def allreduce_grads(params, group=None):
     """Average renderer gradients over ranks in ONE flat all-reduce (4.75 MB for two NeRFs, 8.4 MB for the
     pi_GAN generator: latency-bound on xGMI, so one bucket)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not _exchange(group):
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

@@ -81,14 +81,79 @@ def gate(case: str, stage: str, qty: str, got, ref32, ref64=None, tol: float = T
     return rec
 
 
+GRAD_TOL_SMOOTH = 5e-4     # sin / FiLM networks: relative L2 error of a gradient tensor (norm of the error / norm of the tensor)
+GRAD_TOL_RELU = 5e-3       # ReLU networks: a derivative is a 0/1 switch on a pre-activation's sign; two fp32 pipelines flip a
+#                            handful of (point, unit) pairs and each flip moves a tensor's gradient by ~1e-3 of its norm
+GRAD_ELEM_TOL_SMOOTH = 2e-3  # sin / FiLM networks: max over ELEMENTS of |error| / RMS(tensor) - sensitive to a wrong
+#                              derivative factor on a few units (the rebuilt +-30 sqrt(1 - X^2)), which an L2 norm averages away
+
+
+def gate_grad(case: str, tensor: str, got, ref32, ref64=None, tol: float = GRAD_TOL_SMOOTH, cpu_factor: float = 3.0,
+              elem_tol: float | None = None, check: bool = True, stage: str = "gradient") -> dict:
+    """One gradient tensor of the HIP backward path against the oracle's autograd (same cotangents, same inputs).
+
+      rel_l2      ||got - ref|| / ||ref||, against the fp64 oracle where one is given (else the fp32 oracle)
+      gate        rel_l2 <= tol ("hard"), else - only with ref64 - rel_l2 <= cpu_factor x the fp32 oracle's own rel_l2
+                  from fp64 ("fp64-bound": the HIP path may not sit further from exact arithmetic than the reference's
+                  fp32 autograd does, up to the factor)
+      elem        max |got - ref| / RMS(ref): recorded always; gated (same two bounds, with elem_tol) when elem_tol is
+                  given.  ADVICE r02: per-tensor norms alone would not see a derivative that is wrong on a few units.
+    Leaves one record: both errors, the fp32 oracle's own, the gates and which bound was active."""
+    g = _np64(got).reshape(-1)
+    r32 = _np64(ref32).reshape(-1)
+    ref = r32 if ref64 is None else _np64(ref64).reshape(-1)
+    assert g.shape == ref.shape, (tensor, g.shape, ref.shape)
+    scale = max(float(np.linalg.norm(ref)), 1e-30)
+    rms = max(scale / np.sqrt(max(ref.size, 1)), 1e-30)
+    e_hip, elem_hip = float(np.linalg.norm(g - ref)) / scale, float(np.abs(g - ref).max(initial=0.0)) / rms
+    rec = dict(case=case, stage=stage, qty=tensor, rel_l2_err=e_hip, tol=tol, max_elem_err_over_rms=elem_hip,
+               reference="oracle fp64 autograd" if ref64 is not None else "oracle fp32 autograd", elements=int(ref.size))
+    ok, active = e_hip <= tol, "hard"
+    if ref64 is not None:
+        e_cpu, elem_cpu = float(np.linalg.norm(r32 - ref)) / scale, float(np.abs(r32 - ref).max(initial=0.0)) / rms
+        rec.update(oracle32_rel_l2_from_fp64=e_cpu, oracle32_max_elem_over_rms=elem_cpu, cpu_factor=cpu_factor)
+        if not ok:
+            ok, active = e_hip <= cpu_factor * e_cpu, "fp64-bound"
+    if elem_tol is not None:
+        rec["elem_tol"] = elem_tol
+        ok_e = elem_hip <= elem_tol
+        if not ok_e and ref64 is not None:
+            ok_e = elem_hip <= cpu_factor * rec["oracle32_max_elem_over_rms"]
+            active = "fp64-bound" if ok_e else active
+        ok = ok and ok_e
+    rec.update(active=active, passed=bool(ok))
+    record(**rec)
+    if check:
+        assert ok, rec
+    return rec
+
+
+def gate_grad_samples(case: str, tensor: str, got, idx, val, l2, tol: float, check: bool = True) -> dict:
+    """A gradient tensor against a golden fixture that keeps 512 strided samples + the L2 norm per tensor
+    (tests/golden/make_golden.py: the reference's own autograd).  Both in units of the tensor's norm."""
+    g = _np64(got).reshape(-1)
+    scale = max(float(l2), 1e-12)
+    err = float(np.abs(g[np.asarray(idx)] - _np64(val)).max()) / scale
+    nerr = abs(float(np.sqrt((g ** 2).sum())) - float(l2)) / scale
+    rec = dict(case=case, stage="gradient (golden fixture)", qty=tensor, max_sample_err_over_norm=err,
+               norm_err_over_norm=nerr, tol=tol, reference="reference autograd (fixture)", active="hard",
+               passed=bool(err <= tol and nerr <= tol))
+    record(**rec)
+    if check:
+        assert rec["passed"], rec
+    return rec
+
+
 def write_records(path: str):
     if not RECORDS:
         return
     os.makedirs(os.path.dirname(path), exist_ok=True)
     hard = [r for r in RECORDS if r.get("active") == "hard"]
     soft = [r for r in RECORDS if r.get("active") == "fp64-bound"]
+    grads = [r for r in RECORDS if str(r.get("stage", "")).startswith("gradient")]
     summary = dict(checks=len(RECORDS), hard_gate_active=len(hard), fp64_bound_active=len(soft),
-                   failed=sum(1 for r in RECORDS if r.get("passed") is False),
+                   failed=sum(1 for r in RECORDS if r.get("passed") is False), gradient_records=len(grads),
+                   worst_gradient_rel_l2=max((r["rel_l2_err"] for r in grads if "rel_l2_err" in r), default=0.0),
                    worst_hard=max((r["err_vs_oracle32"] / r["tol"] for r in hard if "err_vs_oracle32" in r and r.get("tol")),
                                   default=0.0),
                    worst_fp64_ratio=max((r["err_vs_fp64"] / max(r["oracle32_vs_fp64"], 1e-30) for r in soft

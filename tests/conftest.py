@@ -21,6 +21,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP path through the C-ABI)")
+    # Diagnostic builds only (tools/diag_build.sh, e.g. a sin range-reduction variant being priced against the parity
+    # records): MI_DIAG_LIB=gpurun_tools/libmirender_sin2.so runs the suite against that library instead of the
+    # product's.  Never set by the driver; the records then carry the library's name.
+    diag = os.environ.get("MI_DIAG_LIB")
+    if diag:
+        from mirender import _lib
+        _lib.LIB_PATH = os.path.join(ROOT, diag)
+        print(f"[conftest] DIAGNOSTIC LIBRARY {_lib.LIB_PATH}", flush=True)
 
 
 def load_golden(name):

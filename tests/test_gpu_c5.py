@@ -84,16 +84,12 @@ def test_c5_film_grads_with_an_image_split_into_ranges(monkeypatch):
         g_raw = A._composite_bwd(raw_d, z_d, rays_d, cot.to(dev()), None, None)
         got, got_film = A._field_backward(pf, rays_d, z_d, raw_d, g_raw, film_d, saved)
         results[tag] = list(got) + [got_film]
-        for name, t in list(zip(names, got)) + [("__film__", got_film)]:
-            r64, r32 = refs[torch.float64][name], refs[torch.float32][name]
-            scale = max(float(r64.norm()), 1e-12)
-            e_hip = float((t.cpu().double() - r64).norm()) / scale
-            e_cpu = float((r32 - r64).norm()) / scale
-            ok = e_hip <= max(5e-4, 3 * e_cpu)
-            parity.record(case=f"C5 film grads 24+48 [{tag}]", stage="field backward", qty=name, err_vs_fp64=e_hip,
-                          oracle32_vs_fp64=e_cpu, tol=5e-4, unit="relative L2 of the tensor",
-                          active="hard" if e_hip <= 5e-4 else "fp64-bound", passed=bool(ok))
-            assert ok, (tag, name, e_hip, e_cpu)
+        recs = [parity.gate_grad(f"C5 film grads 24+48 [{tag}]", name, t.cpu(), refs[torch.float32][name],
+                                 refs[torch.float64][name], tol=parity.GRAD_TOL_SMOOTH,
+                                 elem_tol=parity.GRAD_ELEM_TOL_SMOOTH, check=False, stage="gradient (field backward)")
+                for name, t in list(zip(names, got)) + [("__film__", got_film)]]
+        bad = [r for r in recs if not r["passed"]]
+        assert not bad, bad[0]
     for a_, b_ in zip(results["split, recomputed"], results["split, 3 kept"]):
         assert torch.equal(a_, b_)                             # kept or recomputed: the same ranges, the same sums
     for a_, b_ in zip(results["whole images"], results["split, recomputed"]):

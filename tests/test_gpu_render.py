@@ -316,17 +316,24 @@ def test_get_rays_dropin_matches_numpy(nerf_render, pigan_render, golden):
 
 
 def test_reference_state_dict_layout_loads(nerf_render):
-    """A module with the REFERENCE's parameter names (here rebuilt from nn.Linear pieces, as the reference's
-    classes are) is recognised by layout and takes the fused path."""
-    class RefLikeNeRF(torch.nn.Module):
-        def __init__(self):
-            super().__init__()
-            L = torch.nn.Linear
-            self.layers_pos = torch.nn.ModuleList([L(60, 256)] + [L(256, 256) for _ in range(4)] + [L(316, 256), L(256, 256), L(256, 256)])
-            self.layers_dir = torch.nn.ModuleList([L(256, 256), L(280, 128)])
-            self.output_layer_sigma = L(256, 1)
-            self.output_layer_rgb = L(128, 3)
+    """A module with the REFERENCE's parameter names whose layers describe themselves as the reference's Dense does
+    (`activation_name`, nerf/nerf.py:15; rebuilt here from nn.Linear pieces) is recognised and takes the fused path; the
+    same layout from bare nn.Linear layers says nothing about its activations and is left to the generic path."""
+    class Dense(torch.nn.Linear):
+        def __init__(self, i, o, activation="linear"):
+            super().__init__(i, o)
+            self.activation_name = activation
 
+    class RefLikeNeRF(torch.nn.Module):
+        def __init__(self, L=lambda i, o, act="relu": Dense(i, o, act)):
+            super().__init__()
+            self.layers_pos = torch.nn.ModuleList([L(60, 256)] + [L(256, 256) for _ in range(4)] + [L(316, 256), L(256, 256), L(256, 256)])
+            self.layers_dir = torch.nn.ModuleList([L(256, 256, "linear"), L(280, 128)])
+            self.output_layer_sigma = L(256, 1)
+            self.output_layer_rgb = L(128, 3, "sigmoid")
+
+    from mirender import fields as _f
+    assert _f.as_packed_field(RefLikeNeRF(lambda i, o, act="relu": torch.nn.Linear(i, o))) is None
     from mirender import fields
     sd = synth.state_dict("nerf", seed=6, sharp=True, bias_jitter=0.05)
     m = RefLikeNeRF()

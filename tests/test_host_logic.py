@@ -231,3 +231,21 @@ def test_same_layout_other_arithmetic_is_not_claimed():
     # our own modules name their activations and are claimed
     for cls in (fields.NeRF, fields.TinyNeRF, fields.SirenNeRF, fields.FilmSirenNeRF, fields.FilmSirenNeRFNoDir):
         assert fields.hyper_mismatch(cls(), cls.KIND) is None, cls
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="uses the absence of a GPU as the rank failure")
+@pytest.mark.timeout(300)
+def test_bench_rank_failure_is_relayed_with_a_nonzero_exit_code():
+    """`python bench.py --gpus 2` from a plain shell, on a host where the ranks cannot work (no GPU here): the spawned
+    ranks fail, each failing rank's traceback reaches stderr tagged with its rank, no JSON line is printed and the exit
+    code is non-zero - end to end through the real torch.distributed.run launcher."""
+    import os
+    import subprocess
+    import sys
+    import bench
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.abspath(bench.__file__), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0
+    assert "[bench.py rank 0] FAILED" in r.stderr or "[bench.py rank 1] FAILED" in r.stderr, r.stderr[-2000:]
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())

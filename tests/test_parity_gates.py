@@ -50,3 +50,30 @@ def test_check_render_accepts_the_oracle_and_rejects_errors(sharp):
     with pytest.raises(AssertionError):
         parity.check_render("selfcheck-bad-rgb", bad, ref, f64, rays, 2.0, 6.0, nc, nf, tr, fc, ff, sharp=sharp is True)
     del parity.RECORDS[:]                                                # keep the CPU session's record file empty
+
+
+def test_gate_grad_sees_magnitude_and_single_unit_errors():
+    """The gradient gate (oracle/parity.py:gate_grad): accepts fp32 rounding, rejects a gradient that is 0.2 % too
+    large everywhere (an L2 error), and - with an element gate - a derivative that is wrong on ONE unit of 65 536 (which
+    moves the tensor's L2 error by 4e-5, far inside the norm gate: ADVICE r02 on the rebuilt sin derivative)."""
+    rng = np.random.Generator(np.random.PCG64(1))
+    r64 = rng.standard_normal(65536)
+    r32 = r64.astype(np.float32)
+    ok = parity.gate_grad("t", "w", r32 * np.float32(1 + 1e-6), r32, r64, elem_tol=parity.GRAD_ELEM_TOL_SMOOTH)
+    assert ok["passed"] and ok["active"] == "hard" and ok["rel_l2_err"] < 2e-6
+    with pytest.raises(AssertionError):
+        parity.gate_grad("t", "w", r32 * np.float32(1.002), r32, r64)
+    one = r32.copy()
+    one[1234] += 0.01                                  # 1 % of the RMS on a single element
+    assert parity.gate_grad("t", "w", one, r32, r64)["passed"]            # the norm gate alone does not see it
+    with pytest.raises(AssertionError):
+        parity.gate_grad("t", "w", one, r32, r64, elem_tol=parity.GRAD_ELEM_TOL_SMOOTH)
+    # ReLU-style: the fp32 oracle itself sits 2e-3 from fp64 (a few derivative flips) - the HIP path may be 3x that
+    flips = r64.copy()
+    flips[:40] = 0.0
+    noisy32 = flips.astype(np.float32)
+    other = r64.copy()
+    other[100:150] = 0.0
+    rec = parity.gate_grad("t", "w", other.astype(np.float32), noisy32, r64, tol=1e-4)
+    assert rec["active"] == "fp64-bound" and rec["passed"]
+    del parity.RECORDS[:]
