@@ -177,15 +177,18 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         if constexpr (KB == 8) {
             // 8 K blocks: the row traffic is spread over the whole layer (tools/probes/mfma_store_mix.hip: 8 + 8 quarters
             // per K block run into a mixed read/write ceiling - 80-110 cycles per instruction instead of 17-33 - and
-            // half that density costs a quarter as much).  Loads: slots 0, 4, .., 20 of K blocks 0..5, decoded one K block
-            // later; deferred stores: slots 2, 6, 10, 14 of K blocks 0..7.
+            // half that density costs a quarter as much).  Loads: slots 0, 4, .., 20 of K blocks 1..6, decoded one K block
+            // later (K block 7: slots 0 and 4); deferred stores: slots 2, 6, 10, 14 of K blocks 0..7.
             if constexpr ((slot & 3) == 0) {
-                constexpr int jl = kb * 6 + slot / 4;
-                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 1 && kb <= 6 && jl - 6 < MB * 4) {
+                // K blocks 1..6 (not 0..5): the saved rows are needed by the layer's LAST row only, and every K block
+                // they arrive later is a K block in which 24 registers stay free while all of X is still live (round 3:
+                // siren_bwd_kernel spilled 6 registers, and each scratch reload drains the wave's row traffic)
+                constexpr int jl = (kb - 1) * 6 + slot / 4;
+                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 2 && jl - 6 >= 0 && jl - 6 < MB * 4) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) sv[jl - 6][q] = dsin30_from_saved(sv[jl - 6][q]);
                 }
-                if constexpr (EPI != EPI_LINEAR && kb < 6 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+                if constexpr (EPI != EPI_LINEAR && kb >= 1 && kb < 7 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
             } else if constexpr ((slot & 3) == 2 && slot < 16) {
                 constexpr int js = kb * 4 + slot / 4;
                 if constexpr (js < PREV_MB * 4) {
@@ -408,81 +411,95 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
 // sums T_g = sum_p dL/du X_{l-1}^T and s_g = sum_p dL/du (launch_field_backward), so the chain needs neither
 // the linear output A nor any cross-lane reduction.
 // =========================================================================================
+// dU = dX (.) C with C = 30 cos(30 u) rebuilt from the saved (sign-encoded) X rows; leaves dU in X.  Nothing is stored here:
+// the first chain layer's mid slots write these rows (film_chain_layer), like every other layer's.
 template <int MB>
-__device__ __forceinline__ void film_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ Xs,
-                                               const float* film_row, float* __restrict__ dU, int64_t p, bool valid,
+__device__ __forceinline__ void film_bwd_first(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ Xs, int64_t p,
                                                int h) {
     const f32x4* crow = reinterpret_cast<const f32x4*>(Xs + p * 256 + 4 * h);
-    const lds4_t pg = lds_base(film_row + h * 4);
-    f32x4* drow = reinterpret_cast<f32x4*>(dU + p * 256 + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 cv = crow[m * 8 + rg * 2], gv = pg[m * 8 + rg * 2];
-            f32x4 du;
+            const f32x4 cv = crow[m * 8 + rg * 2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                du[q] = dsin30_from_saved(cv[q]) * dX[m][4 * rg + q];
-                X[m][4 * rg + q] = du[q] * gv[q];
-            }
-            drow[m * 8 + rg * 2] = du;
+            for (int q = 0; q < 4; ++q) X[m][4 * rg + q] = dsin30_from_saved(cv[q]) * dX[m][4 * rg + q];
         }
 }
 
-// One FiLM chain layer (bwd_layer's EPI_FILM case) whose dL/du rows do not burst out of the last row either: FiLM
-// layers carry gamma (.) dL/du in X, so X cannot be stored later as dA can; instead the epilogue parks each dL/du
-// quarter in the register that held its C quarter (`ring`, owned by the kernel), and the NEXT layer's mid slot
-// 4(j%6) of K block j/6 stores it right before loading its own saved-X quarter into the same register (decoded to
-// C = 30 cos(30 u) one K block later, see bwd_layer).
-//   STORE_PREV: ring holds the previous layer's dL/du (-> prev_dU);  KEEP: leave this layer's dL/du in ring
-//   (the caller's next layer stores it) instead of storing it from the epilogue.
-template <int NEXT_BLOCK, bool SCALED, bool FILM_NEXT, bool STORE_PREV, bool KEEP, class BSel>
-__device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, BSel bsel, f32x16 (&acc)[8], f32x16 (&X)[8],
+// One FiLM chain layer j: dX_j = W_{j+1}^T (gamma_{j+1} (.) dU_{j+1}), dU_j = dX_j (.) C_j.
+//
+// On entry X holds dL/du_{j+1} itself (round 2 carried gamma (.) dL/du in X and parked dL/du in the C registers until the
+// next layer stored it: at the layer boundary 128 + 128 such registers were live next to the A fragments, more than the
+// 256 architectural VGPRs - the allocator shuffled ~330 values per layer through AGPRs (v_accvgpr_write / read pairs) and
+// spilled 25 registers to scratch, and every scratch reload is followed by an s_waitcnt vmcnt(0) that drains ALL the
+// wave's outstanding row loads and stores: tools/isa_stats.py).  Now, one K block ahead of its use as
+// the B operand, each block of X is first STORED (the dU_{j+1} rows, a quarter per mid slot) and then scaled in place by
+// gamma_{j+1} (the FiLM row in LDS slot `gamma_row`, read one slot earlier): block kb + 1 in K block kb's slots
+// 1|2|3, 5|6|7, 9|10|11, 13|14|15 (read gamma | store | scale), block 0 in the layer's first hooks.  The same 128
+// multiplies per layer as before, no second copy of anything; X[kb] is dead after K block kb, so X shrinks by a block
+// per K block while the C quarters arrive (slots 0, 4, .., 20 of K blocks 1..6, decoded one K block later).
+// The epilogue leaves dU_j = C_j (.) dX_j in X (LAST: and stores it, there being no next layer to do it).
+// FILM_NEXT: the last stage also DMAs FiLM row `next_film_layer` (= j, what layer j - 1 multiplies by) into the film
+// slot `issue_slot ^ 1`, the one not being read.
+template <int NEXT_BLOCK, bool SCALED, bool FILM_NEXT, bool LAST>
+__device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, f32x16 (&acc)[8], f32x16 (&X)[8],
                                                  f32x4 (&ring)[32], const float* __restrict__ C_rows,
                                                  float* __restrict__ dU, float* __restrict__ prev_dU, int64_t p,
-                                                 bool valid, int issue_slot, int next_film_layer, const float* film_row) {
+                                                 int issue_slot, int next_film_layer, const float* gamma_row) {
     const int h = c.h;
     const lds4_t pv = lds_base(c.smem + kLdsAux0 + h * 16);          // aux slot 0 (the sigma head's row for SCALED)
-    const lds4_t pg = lds_base(film_row + h * 4);
+    const lds4_t pg = lds_base(gamma_row + h * 4);
     const f32x4* srow = reinterpret_cast<const f32x4*>(C_rows + p * 256 + 4 * h);
     f32x4* drow = reinterpret_cast<f32x4*>(dU + p * 256 + 4 * h);
     f32x4* prow = reinterpret_cast<f32x4*>(prev_dU + p * 256 + 4 * h);
+    f32x4 gq;                                                        // gamma quarter read one slot ahead of its use
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
         if constexpr (SCALED) {
             const f32x4 w = pv[piece * 64 + m * 8 + rg];
             acc[m][4 * rg + 0] = w.x * s; acc[m][4 * rg + 1] = w.y * s; acc[m][4 * rg + 2] = w.z * s; acc[m][4 * rg + 3] = w.w * s;
         }       // else: nothing to write, the layer's first MFMAs take srcC = 0 (mma_layer_fn ZERO_START)
+        if constexpr (m == 0) {                                      // before the layer's first MFMA: block 0 of X
+            const f32x4 g = pg[rg * 2];
+            prow[rg * 2] = f32x4{X[0][4 * rg + 0], X[0][4 * rg + 1], X[0][4 * rg + 2], X[0][4 * rg + 3]};
+            X[0][4 * rg + 0] *= g.x; X[0][4 * rg + 1] *= g.y; X[0][4 * rg + 2] *= g.z; X[0][4 * rg + 3] *= g.w;
+        }
     };
     const auto mid = [&](auto kbc, auto sc) {
-        // spread over the layer like bwd_layer's: quarter j = 6 kb + slot / 4 in slots 0, 4, .., 20 of K blocks 0..5
-        constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 6 + slot / 4;
+        constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value;
         if constexpr ((slot & 3) == 0) {
-            if constexpr (kb >= 1 && kb <= 6 && j - 6 < 32) {                    // the quarter loaded one K block ago
+            // C quarters: quarter j = 6 (kb - 1) + slot / 4 in slots 0, 4, .., 20 of K blocks 1..6, decoded one K block later
+            // (K block 7 offers slots 0..15: the last two quarters, loaded in K block 6, are decoded in its slots 0 and 4)
+            constexpr int j = (kb - 1) * 6 + slot / 4;
+            if constexpr (kb >= 2 && j - 6 >= 0 && j - 6 < 32) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ring[j - 6][q] = dsin30_from_saved(ring[j - 6][q]);
             }
-            if constexpr (kb < 6 && j < 32) {
-                constexpr int idx = (j / 4) * 8 + (j % 4) * 2;
-                if constexpr (STORE_PREV) prow[idx] = ring[j];
-                ring[j] = srow[idx];
+            if constexpr (kb >= 1 && kb < 7 && j < 32) ring[j] = srow[(j / 4) * 8 + (j % 4) * 2];
+        } else if constexpr (kb < 7 && slot < 16) {
+            // block kb + 1 of X, quarter rg = slot / 4: gamma read | dU row store | scale in place
+            constexpr int m = kb + 1, rg = slot / 4;
+            if constexpr ((slot & 3) == 1) gq = pg[m * 8 + rg * 2];
+            if constexpr ((slot & 3) == 2)
+                prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+            if constexpr ((slot & 3) == 3) {
+                X[m][4 * rg + 0] *= gq.x; X[m][4 * rg + 1] *= gq.y; X[m][4 * rg + 2] *= gq.z; X[m][4 * rg + 3] *= gq.w;
             }
         }
     };
     const auto post = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value, j = m * 4 + rg;
-        const f32x4 g = pg[m * 8 + rg * 2];
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             o[q] = ring[j][q] * acc[m][4 * rg + q];
-            X[m][4 * rg + q] = o[q] * g[q];
+            X[m][4 * rg + q] = o[q];
         }
-        if constexpr (KEEP) ring[j] = o;
-        else drow[m * 8 + rg * 2] = o;
+        if constexpr (LAST) drow[m * 8 + rg * 2] = o;
     };
-    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true, !SCALED>(c, issue_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
+    const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
+    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true, !SCALED>(c, issue_slot, next_film_layer, NoHook{}, sel_x, acc, pre, post, mid);
 }
 
 template <bool USE_DIR>
@@ -492,9 +509,8 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx_raw(smem, a.packed, a.film + group * (kFilmLayers * kFilmRow));
     const int64_t P = a.points;
-    // rgb head rows x3, sigma row; K blocks 0-1 of hidden_layer_rgb^T; FiLM rows 8 -> film slot 0, 7 -> slot 1
+    // rgb head rows x3, sigma row; K blocks 0-1 of hidden_layer_rgb^T; FiLM row 8 -> film slot 0 (row r lives in slot (8 - r) & 1)
     issue_first_stage<4, 32, true>(c, 0, 0, 8);
-    dma_lump<2>(c, c.frsrc, 7 * (kFilmRow * 4), kLdsFilm0 + kFilmRow);
 
     const int64_t local = tile * 128 + c.wave * 32 + (c.lane & 31);
     const bool valid = local < a.points_per_group;
@@ -506,8 +522,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     if (valid && c.h == 0) reinterpret_cast<f32x4*>(a.grads + (int64_t)(9 * 256) * P)[p] = f32x4{d0, d1, d2, ds};
 
     f32x16 X[8], acc[8];
-    const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
-    const auto film_row = [&](int slot) { return smem + kLdsFilm0 + slot * kFilmRow; };
+    const auto film_row = [&](int r) { return smem + kLdsFilm0 + ((8 - r) & 1) * kFilmRow; };       // FiLM row r's LDS slot
     const auto C = [&](int l) { return a.acts + (int64_t)(8 + 256 * l) * P; };    // saved X_l rows: C_l is rebuilt from them
     const auto dU = [&](int l) { return a.grads + (int64_t)(256 * l) * P; };
 
@@ -525,18 +540,15 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    film_bwd_store<8>(acc, X, C(8), film_row(0), dU(8), p, valid, c.h);                          // hidden_layer_rgb
-    // Chain layer j computes dX_j = W_{j+1}^T dA_{j+1}; its epilogue uses C_j and FiLM row j (film slot (8-j)&1) and
-    // it DMAs FiLM row j-1 into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
-    f32x4 ring[32];                                            // C quarters on the way in, dL/du quarters on the way out
-    film_chain_layer<32, true, true, false, true>(c, 3, ds, sel_x, acc, X, ring, C(7), dU(7), nullptr, p, valid, 1, 6, film_row(1));
+    film_bwd_first<8>(acc, X, C(8), p, c.h);                                                     // hidden_layer_rgb: X = dU_8
+    // Chain layer j multiplies by FiLM row j + 1 (slot (7 - j) & 1) and DMAs row j - what layer j - 1 multiplies by -
+    // into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
+    f32x4 ring[32];                                            // the layer's C quarters, loaded a K block or more ahead
+    film_chain_layer<32, true, true, false>(c, 3, ds, acc, X, ring, C(7), dU(7), dU(8), p, 0, 7, film_row(8));
 #pragma unroll 1
-    for (int j = 6; j >= 1; --j) {                                                               // hidden_layers[5..0]
-        const int fs = (8 - j) & 1;
-        film_chain_layer<32, false, true, true, true>(c, 0, 0.f, sel_x, acc, X, ring, C(j), dU(j), dU(j + 1), p, valid, fs, j - 1,
-                                                      film_row(fs));
-    }
-    film_chain_layer<0, false, false, true, false>(c, 0, 0.f, sel_x, acc, X, ring, C(0), dU(0), dU(1), p, valid, 0, 0, film_row(0));  // input_layer
+    for (int j = 6; j >= 1; --j)                                                                 // hidden_layers[5..0]
+        film_chain_layer<32, false, true, false>(c, 0, 0.f, acc, X, ring, C(j), dU(j), dU(j + 1), p, (7 - j) & 1, j, film_row(j + 1));
+    film_chain_layer<0, false, false, true>(c, 0, 0.f, acc, X, ring, C(0), dU(0), dU(1), p, 1, 0, film_row(1));   // input_layer
 }
 
 // FiLM layer finishing for ONE image (group) g.  T[f][k] = sum_{p in g} dL/du[p][f] X[p][k] (tk = 256, or the 3
@@ -776,10 +788,14 @@ __global__ __launch_bounds__(256) void thin_grad_kernel(ThinBatch tb, int64_t P,
         a3 += hv;
         b0 += s0; b1 += s1; b2 += s2;
     };
+    // eight rows in flight per wave (and four workgroups per CU: BwdBatcher::flush_thin): this kernel is a stream over
+    // P x 1 KiB rows, and with four rows per wave and one workgroup per CU only 16 KiB per CU were in flight - 2.9 TB/s
     int64_t p = p0 + w;
-    for (; p + 12 < p1; p += 16) {
+    for (; p + 28 < p1; p += 32) {
         const f32x4 h0 = row(p), h1 = row(p + 4), h2 = row(p + 8), h3 = row(p + 12);
+        const f32x4 h4 = row(p + 16), h5 = row(p + 20), h6 = row(p + 24), h7 = row(p + 28);
         fma_row(p, h0); fma_row(p + 4, h1); fma_row(p + 8, h2); fma_row(p + 12, h3);
+        fma_row(p + 16, h4); fma_row(p + 20, h5); fma_row(p + 24, h6); fma_row(p + 28, h7);
     }
     for (; p < p1; p += 4) fma_row(p, row(p));
 #pragma unroll
@@ -891,7 +907,7 @@ int64_t bwd_partial_floats(int64_t P) {
     // jobs over all images): an upper bound for any image of at most P points.  launch_field_backward checks every
     // pass's real plan against this figure before it launches anything.
     const int64_t slabs256 = (P + 255) / 256 > 0 ? (P + 255) / 256 : 1;          // BwdBatcher::slabs_for never exceeds this
-    int64_t most = 8 * (slabs256 < 32 ? slabs256 : 32) * kFilmLayerScratch + 2 * (slabs256 < 128 ? slabs256 : 128) * 1280 + 4096;
+    int64_t most = 8 * (slabs256 < 32 ? slabs256 : 32) * kFilmLayerScratch + 2 * (slabs256 < 512 ? slabs256 : 512) * 1280 + 4096;
     for (int kind : {0, 1, 4}) {                                       // the others: every job of the pass at once
         const int64_t n = batched_partial_floats(kind, P);
         if (n > most) most = n;
@@ -918,11 +934,13 @@ struct BwdBatcher {
     ReduceBatch all{};
     int n_red = 0, max_rec = 0;
 
-    static int slabs_for(int64_t P, int njobs) {
+    static int slabs_for(int64_t P, int njobs, int per_cu = 1) {
         // one workgroup per CU over the whole launch: the workgroups of a launch do equal work, so a single wave of
-        // them has no tail, and fewer slabs mean fewer partial tiles to write and to sum
-        int64_t s = (256 + njobs - 1) / njobs;
-        if (s > 256) s = 256;
+        // them has no tail, and fewer slabs mean fewer partial tiles to write and to sum.  (per_cu = 4 for the thin
+        // gradients: a 256-thread streaming kernel with no LDS to speak of needs several workgroups per CU to keep
+        // enough loads in flight, and its records are 4 KiB, not 256 KiB.)
+        int64_t s = (256 * per_cu + njobs - 1) / njobs;
+        if (s > 256 * per_cu) s = 256 * per_cu;
         const int64_t most = (P + 255) / 256;              // slabs of at least 256 points
         if (s > most) s = most;
         return (int)(s < 1 ? 1 : s);
@@ -987,7 +1005,7 @@ struct BwdBatcher {
     }
     int flush_thin() {
         if (!n_thin) return 0;
-        const int slabs = slabs_for(P, n_thin), slab = slab_pts_for(P, slabs);
+        const int slabs = slabs_for(P, n_thin, 4), slab = slab_pts_for(P, slabs);
         const int n_slabs = (int)((P + slab - 1) / slab);
         for (int i = 0; i < n_thin; ++i) {
             thin.partial[i] = take((int64_t)n_slabs * 1024);

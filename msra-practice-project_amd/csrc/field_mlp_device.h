@@ -137,6 +137,36 @@ __device__ __forceinline__ void mma_chunk(Ctx& c, const float* chunk, const f32x
     // 2048-cycle row).  Reading only the FIRST operand of the next row a few MFMAs ahead hides nearly all of it
     // for 4 registers; the other reads follow at the row start, behind that MFMA.
     f32x4 a_first = a4[0];
+    if constexpr (ORDER & 16) {
+        // A layer's LAST K block run m-major over all four rows (ORDER bit 4): block m's chain completes after its own 16
+        // MFMAs, and post(m - 1, part) rides behind every 4th MFMA of block m - the epilogue is spread over the whole K
+        // block (128 MFMAs) instead of its last row (32).  For epilogues that STORE a row quarter per part (the training
+        // forward of the sin layers, whose encoded rows cannot be deferred to the next layer) that is one 1 KiB store per
+        // 256 cycles and wave instead of one per 64: 32 of them inside one 2 048-cycle row ask for the CU's whole
+        // 64 B/clk vector-memory path.  Same MFMAs, same A reads (4 per block), same rounding (a chain is still summed in
+        // k order).
+        static_for<MB>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            f32x4 a[4];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) a[rg] = (m == 0 && rg == 0) ? a_first : a4[(rg * MB + m) * 64];
+            static_for<4>([&](auto rgc) {
+                constexpr int rg = decltype(rgc)::value;
+                static_for<4>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rg][q], b[4 * rg + q], acc[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (m >= 1 && q == 1) post(ic<(m >= 1 ? m - 1 : 0)>{}, rgc);
+                    if constexpr (rg == 0 && q == 3) slot(mc);
+                    // the 2 MB mid slots a layer's last K block offers (the previous layer's deferred row quarters)
+                    if constexpr (!std::is_same<Mid, NoHook>::value && (rg & 1) == 1 && q == 3) mid(ic<KBI>{}, ic<2 * m + rg / 2>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        });
+        static_for<4>([&](auto pc) { post(ic<MB - 1>{}, pc); });
+        return;
+    }
     static_for<4>([&](auto rgc) {
         constexpr int rg = decltype(rgc)::value;
         MI_ROW_STAMP(c);
@@ -307,7 +337,7 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
 // HOOKS: pre(m, part) / post(m, part) are the sliced accumulator start / epilogue of mma_chunk; without them
 // init(acc) runs as one lump before the first MFMA and the caller applies its epilogue after the call.
 template <int KB, int MB, int PAR0_UNUSED, int NEXT_AUX, int NEXT_BLOCK, bool FILM, bool HOOKS = false, bool ZERO_START = false,
-          class Init, class BSel, class Pre = NoHook, class Post = NoHook, class Mid = NoHook>
+          bool SPREAD_LAST = false, class Init, class BSel, class Pre = NoHook, class Post = NoHook, class Mid = NoHook>
 __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film_layer, Init init, BSel bsel,
                                              f32x16 (&acc)[8], Pre pre = Pre{}, Post post = Post{}, Mid mid = Mid{}) {
     static_assert(KB >= 2, "every MFMA layer has at least two K blocks");
@@ -318,8 +348,9 @@ __device__ __forceinline__ void mma_layer_fn(Ctx& c, int aux_slot, int next_film
         constexpr int left = KB - 2 * (i + 1);                       // K blocks after this stage
         constexpr int next_blocks = left >= 2 ? 2 : (left > 0 ? left : 0);
         constexpr int zs = ZERO_START ? 8 : 0;         // ORDER bit 3: the layer's first MFMAs take srcC = 0
-        constexpr int order0 = HOOKS ? ((kb0 == 0 ? 1 | zs : 0) | (kb0 == KB - 1 ? 2 : 0)) : 0;
-        constexpr int order1 = HOOKS ? (kb0 + 1 == KB - 1 ? 2 : 0) : 0;
+        constexpr int last = SPREAD_LAST ? 16 : 2;      // the last K block: epilogue in its last row, or spread over all of it
+        constexpr int order0 = HOOKS ? ((kb0 == 0 ? 1 | zs : 0) | (kb0 == KB - 1 ? last : 0)) : 0;
+        constexpr int order1 = HOOKS ? (kb0 + 1 == KB - 1 ? last : 0) : 0;
         __syncthreads();
         if constexpr (i == 0 && !HOOKS) init(acc);
         const float* buf = c.smem + kLdsChunk0 + c.buf * kLdsChunk;
@@ -369,6 +400,10 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
     f32x4 bias_q[2], g_q[2], bb_q[2];
     constexpr bool kSinAct = ACT == ACT_SIN30 || ACT == ACT_FILM;
+    // epilogues that store their own rows (training forward of a sin layer: the saved rows are an ENCODING of X that the
+    // registers do not carry on, so they cannot be deferred to the next layer's slots) are spread over the whole last K
+    // block (mma_chunk ORDER bit 4); K = 3 layers start their accumulators in that same K block's first hooks - not them
+    constexpr bool kSpread = SAVE && kSinAct;
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
         // The chain starts at zero and post adds the bias (see init_acc).  Plain layers need nothing here: their first
@@ -445,9 +480,9 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
                 prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             }
         };
-        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
+        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3, kSpread>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
     } else {
-        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
+        mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3, kSpread>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
     }
 }
 

@@ -42,29 +42,27 @@ __device__ __forceinline__ float hw_turns(float t) {
     const float lo = fmaf(t, c_lo, fmaf(t, c_hi, -hi));
     return (hi - rintf(hi)) + lo;
 }
-// MI_SIN_VARIANT (diagnostic builds, tools/diag_build.sh sin<k>; the product is built with the default):
-//   0  t = fl(30 u); n = rndne(fl(t c_hi)); r = fma(t, c_lo, fma(t, c_hi, -n))      5 VALU + v_sin   2.5e-7 / 4.9e-8
-//   1  t = fl(30 u); n = rndne(fl(t c_hi)); r = fma(t, c_hi, -n)   (no c_lo term)   4 VALU + v_sin
-//   2  t = fl(30 u); r = fract(fl(t c_hi))                                           3 VALU + v_sin
-//   3  r = fract(fl(u K)), K = fl(30 / 2 pi)   (the product 30 u is never rounded)   2 VALU + v_sin
-// (errors against sin(fl(30 u)) over the probe's |u| < 40: tools/probes/sin_variants.hip; what they cost in parity and
-// buy in MFMA-busy time: DESIGN.md 4.1)
+// The range reduction of the MFMA layers' epilogues (hw_turns30_x4 below), priced in round 3 on MI355X against the parity
+// records (tools/sin_variants_round.sh, profiles/r03_sin_variants.log; VALU instructions per element before the v_sin):
+//   0  t = fl(30 u); n = rndne(fl(t c_hi)); r = fma(t, c_lo, fma(t, c_hi, -n))    5   SirenNeRF 88.3 %  FiLM 86.3 % of peak
+//   1  t = fl(30 u); n = rndne(fl(t c_hi)); r = fma(t, c_hi, -n)   (no c_lo)      4             88.8         86.9
+//   2  t = fl(30 u); r = fract(fl(t c_hi))                                        3             89.3         87.5
+//   3  r = fract(fl(u K)), K = fl(30 / 2 pi)                                      2             90.2         88.3
+// Variant 0 follows the reference's fp32 expression torch.sin(30 * x) to 2.5e-7 whatever |u|.  Variant 3 rounds ONE
+// product of magnitude |30 u| / 2 pi where the reference rounds one product of magnitude |30 u|: against sin(fl(30 u)) it
+// is off by up to |30 u| x 6e-8 (1.5e-6 for |u| < 0.5, 1.2e-5 for |u| < 4), but against the EXACT sin(30 u) it is as close
+// as the reference's own fp32 evaluation is (probe over |u| < 40: max 7.4e-5 / rms 8.3e-6 against 6.1e-5 / 6.5e-6 for libm
+// on the rounded product) - an equally valid fp32 evaluation that rounds elsewhere.  What it costs in parity: the worst
+// SIREN / FiLM record on rgb / acc / depth moves from 0.012 to 0.034 of its flat 1e-4 gate (FiLM 0.007 -> 0.009), the
+// fp64 comparison (no further from exact arithmetic than 1.5x the fp32 oracle) and every gradient record hold.  The
+// product uses 3 in the epilogues of the MFMA layers and keeps 0 for the K = 3 input layer (hw_sin30 below), whose
+// argument - raw coordinates times weights of order 1 - is the largest of the network.
 #ifndef MI_SIN_VARIANT
-#define MI_SIN_VARIANT 0
+#define MI_SIN_VARIANT 3
 #endif
 __device__ __forceinline__ float hw_turns30(float u) {
 #pragma clang fp contract(off)
-#if MI_SIN_VARIANT == 0
     return hw_turns_fast(30.f * u);
-#elif MI_SIN_VARIANT == 1
-    const float c_hi = 0.15915494309189535f;
-    const float t = 30.f * u;
-    return fmaf(t, c_hi, -rintf(t * c_hi));
-#elif MI_SIN_VARIANT == 2
-    return __builtin_amdgcn_fractf((30.f * u) * 0.15915494309189535f);
-#else
-    return __builtin_amdgcn_fractf(u * 4.774648292756860f);                    // 30 / (2 pi)
-#endif
 }
 #if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1     // diagnostic builds only (tools/diag_build.sh): no activation work at all
 __device__ __forceinline__ float hw_sin30(float u) { return u; }
@@ -93,23 +91,8 @@ __device__ __forceinline__ f32x2 hw_turns_x2(f32x2 t) {
 }
 __device__ __forceinline__ f32x2 hw_turns30_x2(f32x2 u) {
 #pragma clang fp contract(off)
-#if MI_SIN_VARIANT == 0
     const f32x2 w0 = {30.f, 30.f};
     return hw_turns_x2(u * w0);
-#elif MI_SIN_VARIANT == 1
-    const f32x2 w0 = {30.f, 30.f}, c_hi = {0.15915494309189535f, 0.15915494309189535f};
-    const f32x2 t = u * w0, hi = t * c_hi;
-    const f32x2 n = {rintf(hi.x), rintf(hi.y)};
-    return __builtin_elementwise_fma(t, c_hi, -n);
-#elif MI_SIN_VARIANT == 2
-    const f32x2 w0 = {30.f, 30.f}, c_hi = {0.15915494309189535f, 0.15915494309189535f};
-    const f32x2 hi = (u * w0) * c_hi;
-    return f32x2{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y)};
-#else
-    const f32x2 k = {4.774648292756860f, 4.774648292756860f};
-    const f32x2 hi = u * k;
-    return f32x2{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y)};
-#endif
 }
 __device__ __forceinline__ f32x2 hw_sin30_x2(f32x2 u) {
     const f32x2 r = hw_turns30_x2(u);
