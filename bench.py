@@ -268,17 +268,26 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
 
 def psnr_vs_ref(dev):
     """The metric's "PSNR vs ref" clause on trained results: student pairs fitted to the synthetic teacher scene of
-    oracle/fit_ref.py (24x24 views, 16+16 samples, the loop of nerf/train_nerf.py:124-176) by the HIP path and by the
-    reference loop on the CPU - same initial weights, rays and jitter; held-out-view PSNR of both.  TinyNeRF (PE + ReLU):
-    60 Adam steps of 256 rays at 5e-4; SirenNeRF (the sin family): 15 Adam steps over all 3 456 rays at 1e-5 - regimes
-    in which the CPU loop itself is reproducible under a 1e-6 perturbation of its initial weights to 1e-3 / 5e-5 in the losses (tests/test_gpu_psnr.py gates them hard).
-    Part of the CPU-baseline leg (the only place bench.py touches oracle/)."""
+    oracle/fit_ref.py (24x24 views, 16+16 samples, the loop of nerf/train_nerf.py:124-176) by the HIP path and by the same
+    loop on the CPU - same initial weights, rays and jitter; held-out-view PSNR of both.  TinyNeRF (PE + ReLU): 60 Adam
+    steps of 256 rays at 5e-4, CPU side = the oracle's loop run here; SirenNeRF (the sin family): 15 Adam steps over all
+    3 456 rays at 1e-5, CPU side = the REFERENCE's own code run in the build container (tests/golden/fit_r03_siren_adam.npz:
+    a live CPU fit of an 8x256 sin pair costs ~2 minutes on this host).  Both regimes are reproducible under a 1e-6
+    perturbation of the initial weights to < 1e-3 dB (tests/test_gpu_psnr.py gates them hard).  Part of the CPU-baseline
+    leg (the only place bench.py touches oracle/)."""
     from mirender import fields, render_core
     from oracle import fit_ref, render_ref as R
     out = {}
-    for student, lr0, batch, steps in (("tiny_nerf", 5e-4, 256, 60), ("siren_nerf", 1e-5, 0, 15)):
+    for student, lr0, batch, steps, fixture in (("tiny_nerf", 5e-4, 256, 60, None), ("siren_nerf", 1e-5, 0, 15, "fit_r03_siren_adam")):
         scene = fit_ref.Scene(student=student)
-        cpu_losses, cpu_psnr, _ = fit_ref.fit_cpu(scene, steps, batch, lr0=lr0)
+        if fixture is None:
+            cpu_losses, cpu_psnr, _ = fit_ref.fit_cpu(scene, steps, batch, lr0=lr0)
+            cpu_side = "oracle loop run on this host's CPU"
+        else:
+            with np.load(os.path.join(ROOT, "tests", "golden", fixture + ".npz")) as f:
+                cpu_losses, cpu_psnr = [float(x) for x in f["losses"]], float(f["heldout_psnr"])
+                assert int(f["steps"]) == steps and abs(float(f["lr0"]) - lr0) < 1e-12
+            cpu_side = f"the reference's own code, build container (tests/golden/{fixture}.npz)"
         cm, fm = fields.field_from_state_dict(scene.student_init[0], dev), fields.field_from_state_dict(scene.student_init[1], dev)
         opt = fit_ref.make_optimizer(list(cm.parameters()) + list(fm.parameters()), "adam", lr0)
         loss, worst = None, 0.0
@@ -299,7 +308,7 @@ def psnr_vs_ref(dev):
         hip_psnr = R.psnr(held[3].cpu().numpy(), scene.images[-1].numpy())
         out[student] = {"hip_db": hip_psnr, "cpu_reference_loop_db": cpu_psnr, "diff_db": hip_psnr - cpu_psnr,
                         "final_loss_hip": float(loss), "final_loss_cpu": cpu_losses[-1], "max_rel_loss_diff": worst,
-                        "regime": f"{steps} Adam steps (lr {lr0:g}) of {batch or 'all 3456'} rays"}
+                        "regime": f"{steps} Adam steps (lr {lr0:g}) of {batch or 'all 3456'} rays", "cpu_side": cpu_side}
     # the headline pair stays at the top level (round-2 readers), the per-family results under "families"
     top = dict(out["tiny_nerf"])
     top["families"] = out

@@ -185,8 +185,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
                 // siren_bwd_kernel spilled 6 registers, and each scratch reload drains the wave's row traffic)
                 constexpr int jl = (kb - 1) * 6 + slot / 4;
                 if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 2 && jl - 6 >= 0 && jl - 6 < MB * 4) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) sv[jl - 6][q] = dsin30_from_saved(sv[jl - 6][q]);
+                    sv[jl - 6] = dsin30_from_saved_x4(sv[jl - 6]);
                 }
                 if constexpr (EPI != EPI_LINEAR && kb >= 1 && kb < 7 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
             } else if constexpr ((slot & 3) == 2 && slot < 16) {
@@ -198,8 +197,7 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
             }
         } else
         if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 1 && kb < 5 && slot < 16 && (slot & 1) == 0 && j - 8 < MB * 4) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sv[j - 8][q] = dsin30_from_saved(sv[j - 8][q]);
+            sv[j - 8] = dsin30_from_saved_x4(sv[j - 8]);
         }
         if constexpr (KB != 8 && kb < 4 && slot < 16) {          // 4 K blocks: all 16 mid slots of rows 1-2 are needed
             if constexpr ((slot & 1) == 0) {
@@ -463,7 +461,8 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, f32
         if constexpr (m == 0) {                                      // before the layer's first MFMA: block 0 of X
             const f32x4 g = pg[rg * 2];
             prow[rg * 2] = f32x4{X[0][4 * rg + 0], X[0][4 * rg + 1], X[0][4 * rg + 2], X[0][4 * rg + 3]};
-            X[0][4 * rg + 0] *= g.x; X[0][4 * rg + 1] *= g.y; X[0][4 * rg + 2] *= g.z; X[0][4 * rg + 3] *= g.w;
+            const f32x4 t = f32x4{X[0][4 * rg + 0], X[0][4 * rg + 1], X[0][4 * rg + 2], X[0][4 * rg + 3]} * g;
+            X[0][4 * rg + 0] = t.x; X[0][4 * rg + 1] = t.y; X[0][4 * rg + 2] = t.z; X[0][4 * rg + 3] = t.w;
         }
     };
     const auto mid = [&](auto kbc, auto sc) {
@@ -473,8 +472,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, f32
             // (K block 7 offers slots 0..15: the last two quarters, loaded in K block 6, are decoded in its slots 0 and 4)
             constexpr int j = (kb - 1) * 6 + slot / 4;
             if constexpr (kb >= 2 && j - 6 >= 0 && j - 6 < 32) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) ring[j - 6][q] = dsin30_from_saved(ring[j - 6][q]);
+                ring[j - 6] = dsin30_from_saved_x4(ring[j - 6]);
             }
             if constexpr (kb >= 1 && kb < 7 && j < 32) ring[j] = srow[(j / 4) * 8 + (j % 4) * 2];
         } else if constexpr (kb < 7 && slot < 16) {
@@ -484,18 +482,15 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, f32
             if constexpr ((slot & 3) == 2)
                 prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
             if constexpr ((slot & 3) == 3) {
-                X[m][4 * rg + 0] *= gq.x; X[m][4 * rg + 1] *= gq.y; X[m][4 * rg + 2] *= gq.z; X[m][4 * rg + 3] *= gq.w;
+                const f32x4 t = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]} * gq;
+                X[m][4 * rg + 0] = t.x; X[m][4 * rg + 1] = t.y; X[m][4 * rg + 2] = t.z; X[m][4 * rg + 3] = t.w;
             }
         }
     };
     const auto post = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value, j = m * 4 + rg;
-        f32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            o[q] = ring[j][q] * acc[m][4 * rg + q];
-            X[m][4 * rg + q] = o[q];
-        }
+        const f32x4 o = ring[j] * f32x4{acc[m][4 * rg + 0], acc[m][4 * rg + 1], acc[m][4 * rg + 2], acc[m][4 * rg + 3]};
+        X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
         if constexpr (LAST) drow[m * 8 + rg * 2] = o;
     };
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };

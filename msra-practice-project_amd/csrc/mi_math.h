@@ -126,6 +126,20 @@ __device__ __forceinline__ float dsin30_from_saved(float xs) {
     const float y = fmaf(xs * -900.f, xs, 900.f);
     return __uint_as_float((__float_as_uint(xs) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y))));
 }
+// Four saved values (one row quarter) at a time: the squares and the fma as two packed instructions each - 3 instead of 4
+// VALU instructions per element, same roundings as the scalar form (fl(fl(x * -900) * x + 900)).
+typedef float f32x4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4d dsin30_from_saved_x4(f32x4d xs) {
+#pragma clang fp contract(off)
+    const f32x4d k = {900.f, 900.f, 900.f, 900.f};
+    const f32x4d y = __builtin_elementwise_fma(xs * -900.f, xs, k);
+    f32x4d o;
+    o.x = __uint_as_float((__float_as_uint(xs.x) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.x))));
+    o.y = __uint_as_float((__float_as_uint(xs.y) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.y))));
+    o.z = __uint_as_float((__float_as_uint(xs.z) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.z))));
+    o.w = __uint_as_float((__float_as_uint(xs.w) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.w))));
+    return o;
+}
 struct SinSaved2 { f32x2 s, saved; };
 __device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {
     const f32x2 r = hw_turns30_x2(u);

@@ -18,6 +18,7 @@ Fixture families:
   F8 metrics       pytorch_ssim.ssim / mse / psnr of synthetic frame pairs (nerf/test_nerf.py:102-104)
   F9 video         render_video / render_image / render_image_np over two poses; ref_layouts.json (make_r02)
   ref_layer_attrs.json   each layer object's class / activation_name / w_0 in the reference's field classes (make_r03)
+  F10 fit_r03_*    training trajectories of the reference's own code on the teacher scene (make_r03_fit)
 """
 import contextlib
 import os
@@ -299,6 +300,65 @@ def make_r03(nm, pm):
     print("ref_layer_attrs.json", {k: len(v["layers"]) for k, v in out.items()})
 
 
+FIT_REGIMES = [  # name, student kind, optimiser, lr, steps (every step takes all 3 456 training rays)
+    ("fit_r03_siren_adam", "siren_nerf", "adam", 1e-5, 15), ("fit_r03_film_adam", "film_siren_nerf", "adam", 1e-5, 15),
+    ("fit_r03_siren_sgd", "siren_nerf", "sgd", 2e-4, 8), ("fit_r03_film_sgd", "film_siren_nerf", "sgd", 2e-4, 8),
+    ("fit_r03_siren_chaotic", "siren_nerf", "adam", 5e-4, 30),      # 256-ray batches: round 2's regime, diagnostic only
+]
+
+
+def make_r03_fit(nr, nm, pm):
+    """F10 fit_r03_*: the loop of nerf/train_nerf.py:124-176 run by the REFERENCE's own code on this container's CPU - its
+    render_rays (nerf/render.py:106-147), its SirenNeRF / FilmSirenNeRF modules, torch.optim.Adam / SGD - on the synthetic
+    teacher scene of oracle/fit_ref.py (rays, teacher images, initial weights, per-step jitter: inputs), so that the GPU
+    tests compare the HIP path's training trajectory with the reference's without re-running a 1-2 minute CPU fit per
+    regime on the GPU box.  Stored: the loss of every step, the held-out view and its PSNR, and - to document the
+    regime's own noise - the PSNR of the same run from initial weights perturbed by 1e-6 relative.  The oracle's own loop
+    (fit_ref.fit_cpu) must reproduce the trajectory (asserted here: 1e-4 relative, the two being different code paths
+    through the same arithmetic)."""
+    from oracle import fit_ref
+
+    def run(scene, student, optimizer, lr0, steps, batch, init):
+        film = scene.film
+        models = [ref_model(student, nm, pm, {k: v.clone() for k, v in sd.items()}, film) for sd in init]
+        params = [p for m in models for p in m.parameters()]
+        opt = fit_ref.make_optimizer(params, optimizer, lr0)
+        losses = []
+        for step in range(steps):
+            rays, rgb, tr = scene.batch(step, batch)
+            with injected_rand([tr]):
+                out = nr.render_rays(rays, fit_ref.NEAR, fit_ref.FAR, models[0], models[1], scene.nc, scene.nf)
+            loss = torch.mean((out[3] - rgb) ** 2) + torch.mean((out[0] - rgb) ** 2)          # train_nerf.py:158-166
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            for g in opt.param_groups:
+                g["lr"] = fit_ref.lr_at(step + 1, lr0)                                        # :170-175
+            losses.append(float(loss.detach()))
+        with torch.no_grad(), injected_rand([scene.heldout_jitter()]):
+            held = nr.render_rays(scene.rays[-1], fit_ref.NEAR, fit_ref.FAR, models[0], models[1], scene.nc, scene.nf)
+        return np.array(losses), held[3].numpy(), oref.psnr(held[3].numpy(), scene.images[-1].numpy())
+
+    for name, student, optimizer, lr0, steps in FIT_REGIMES:
+        batch = 256 if name.endswith("chaotic") else 0
+        scene = fit_ref.Scene(student=student)
+        losses, held, psnr = run(scene, student, optimizer, lr0, steps, batch, scene.student_init)
+        o_losses, o_psnr, _ = fit_ref.fit_cpu(scene, steps, batch, lr0=lr0, optimizer=optimizer)
+        rel = float(np.abs(np.array(o_losses) - losses).max() / losses.min())
+        if not name.endswith("chaotic"):
+            assert rel <= 1e-4 and abs(o_psnr - psnr) <= 2e-3, (name, rel, o_psnr, psnr)
+        rng = np.random.Generator(np.random.PCG64(9))
+        pert = tuple({k: v * torch.from_numpy((1 + 1e-6 * rng.standard_normal(tuple(v.shape))).astype(np.float32)) for k, v in sd.items()}
+                     for sd in scene.student_init)
+        p_losses, _, p_psnr = run(scene, student, optimizer, lr0, steps, batch, pert)
+        save(name, losses=losses, heldout_rgb=held, heldout_psnr=np.float64(psnr), lr0=np.float64(lr0), steps=steps, batch=batch,
+             optimizer=np.array(optimizer), student=np.array(student), digest_c=np.array(synth.digest(scene.student_init[0])),
+             digest_f=np.array(synth.digest(scene.student_init[1])), oracle_loop_max_rel_loss_diff=np.float64(rel),
+             oracle_loop_psnr=np.float64(o_psnr), perturbed_1e6_psnr=np.float64(p_psnr),
+             perturbed_1e6_max_rel_loss_diff=np.float64(np.abs(p_losses - losses).max() / losses.min()))
+        print(name, "loss", losses[0], "->", losses[-1], "psnr", psnr, "| oracle loop", o_psnr, "rel", rel, "| perturbed 1e-6", p_psnr, flush=True)
+
+
 def main():
     if "--only-metrics" in sys.argv:
         make_metrics()
@@ -307,6 +367,9 @@ def main():
     nr, nm, nd, pr, pm = load_reference()
     if "--only-r03" in sys.argv:
         make_r03(nm, pm)
+        return
+    if "--only-r03-fit" in sys.argv:
+        make_r03_fit(nr, nm, pm)
         return
     if "--only-r02" in sys.argv:
         make_r02(nr, nm, nd, pr, pm)

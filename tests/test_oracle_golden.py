@@ -254,3 +254,25 @@ def test_rays_rgba_table_restatement(golden):
     assert np.array_equal(tab[:H * W, 0:3], g["rays_o"].reshape(-1, 3)) and np.array_equal(tab[H * W:, 3:6], g["rays_d"].reshape(-1, 3))
     a = imgs[..., 3:].reshape(-1, 1)
     assert np.array_equal(tab[:, 6:9], imgs[..., :3].reshape(-1, 3) * a + (1. - a)) and np.array_equal(tab[:, 9:], a)
+
+
+def test_fit_trajectory_fixtures_are_reproduced_by_the_oracle_loop(golden):
+    """F10 (fit_r03_*): training trajectories of the REFERENCE's own code (its render_rays, its SirenNeRF / FilmSirenNeRF
+    modules, torch's optimisers; tests/golden/make_golden.py --only-r03-fit) on the teacher scene.  The generator asserted
+    that the oracle's loop (oracle/fit_ref.py:fit_cpu) reproduces every step of every regime (it did, bit for bit:
+    oracle_loop_max_rel_loss_diff = 0); here, on whatever CPU runs this suite, the first two steps of the cheapest
+    regime are replayed (forward, gradients, one SGD update - ~10 s) and the stored figures are checked for sanity."""
+    from oracle import fit_ref, synth
+    for name in ("fit_r03_siren_adam", "fit_r03_film_adam", "fit_r03_siren_sgd", "fit_r03_film_sgd", "fit_r03_siren_chaotic"):
+        g = golden(name)
+        assert g["losses"].shape == (int(g["steps"]),) and g["heldout_rgb"].shape == (24 * 24, 3)
+        assert float(g["oracle_loop_max_rel_loss_diff"]) <= (1.0 if name.endswith("chaotic") else 1e-4)
+        if not name.endswith("chaotic"):       # the hard regimes are quiet under a 1e-6 perturbation of the initial weights
+            assert abs(float(g["perturbed_1e6_psnr"]) - float(g["heldout_psnr"])) <= 2e-3
+            assert float(g["perturbed_1e6_max_rel_loss_diff"]) <= 2e-3
+            assert g["losses"][-1] < 0.3 * g["losses"][0]
+    g = golden("fit_r03_siren_sgd")
+    scene = fit_ref.Scene(student="siren_nerf")
+    assert synth.digest(scene.student_init[0]) == str(g["digest_c"])
+    losses, _, _ = fit_ref.fit_cpu(scene, 2, 0, lr0=float(g["lr0"]), optimizer="sgd")
+    assert np.abs(np.array(losses) - g["losses"][:2]).max() <= 1e-5 * g["losses"][0]
