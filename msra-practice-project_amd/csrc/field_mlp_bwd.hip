@@ -100,17 +100,26 @@ struct BwdArgs {
 unsigned long long* g_bwd_stamps = nullptr;       // set by mi_debug_set_stamps (api.hip), diagnostic build only
 #endif
 
-// dA = dX (.) relu'(H) with H the saved post-ReLU activation; stores dA rows and leaves them in X.
+// The saved row of the chain's first epilogue (the 128-wide dir layer), loaded at the top of the kernel: its latency
+// overlaps the first weight stage's DMA and the head gradients instead of following them.
 template <int MB>
-__device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ H,
+__device__ __forceinline__ void load_saved_row(f32x4 (&sv)[MB * 4], const float* __restrict__ rows, int64_t ld, int64_t p, int h) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(rows + p * ld + 4 * h);
+#pragma unroll
+    for (int j = 0; j < MB * 4; ++j) sv[j] = row[(j / 4) * 8 + (j % 4) * 2];
+}
+
+// dA = dX (.) relu'(H) with H the saved post-ReLU activation (`hsv`, loaded by load_saved_row); stores dA rows and leaves
+// them in X.
+template <int MB>
+__device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const f32x4 (&hsv)[MB * 4],
                                                float* __restrict__ dA, int64_t ld, int64_t p, bool valid, int h) {
-    const f32x4* hrow = reinterpret_cast<const f32x4*>(H + p * ld + 4 * h);
     f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 hv = hrow[m * 8 + rg * 2];
+            const f32x4 hv = hsv[m * 4 + rg];
             f32x4 o;
             o.x = hv.x > 0.f ? dX[m][4 * rg + 0] : 0.f;
             o.y = hv.y > 0.f ? dX[m][4 * rg + 1] : 0.f;
@@ -255,6 +264,8 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
     const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
+    f32x4 hsv[16];
+    load_saved_row<4>(hsv, acts(TINY ? 6 : 11), 128, p, c.h);
     MI_STAMP(a, 0);
 
     __syncthreads();                                        // head rows (and K block 0) have landed
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    relu_bwd_store<4>(acc, X, acts(TINY ? 6 : 11), grads(TINY ? 4 : 9), 128, p, valid, c.h);   // dA of the dir layer
+    relu_bwd_store<4>(acc, X, hsv, grads(TINY ? 4 : 9), 128, p, valid, c.h);                    // dA of the dir layer
     MI_STAMP(a, 1);
 
     int slot = 0;
@@ -325,18 +336,15 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
 
 // dA = dX (.) C with C = 30 cos(30 A) rebuilt from the saved (sign-encoded) X rows; stores dA rows, leaves them in X.
 template <int MB>
-__device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ Xs,
+__device__ __forceinline__ void sin_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const f32x4 (&xsv)[MB * 4],
                                               float* __restrict__ dA, int64_t ld, int64_t p, bool valid, int h) {
-    const f32x4* crow = reinterpret_cast<const f32x4*>(Xs + p * ld + 4 * h);
     f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 xv = crow[m * 8 + rg * 2];
-            f32x4 o;
-            o.x = dsin30_from_saved(xv.x) * dX[m][4 * rg + 0]; o.y = dsin30_from_saved(xv.y) * dX[m][4 * rg + 1];
-            o.z = dsin30_from_saved(xv.z) * dX[m][4 * rg + 2]; o.w = dsin30_from_saved(xv.w) * dX[m][4 * rg + 3];
+            const f32x4 o = dsin30_from_saved_x4(xsv[m * 4 + rg]) *
+                            f32x4{dX[m][4 * rg + 0], dX[m][4 * rg + 1], dX[m][4 * rg + 2], dX[m][4 * rg + 3]};
             X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
             drow[m * 8 + rg * 2] = o;
         }
@@ -367,6 +375,8 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
     const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
+    f32x4 xsv[16];
+    load_saved_row<4>(xsv, acts(10), 128, p, c.h);
 
     __syncthreads();
     {   // dX_d = W_rgb^T d_pre_rgb (128 features)
@@ -382,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    sin_bwd_store<4>(acc, X, acts(10), grads(9), 128, p, valid, c.h);                          // dA layers_dir.1 (X_d rows)
+    sin_bwd_store<4>(acc, X, xsv, grads(9), 128, p, valid, c.h);                               // dA layers_dir.1 (X_d rows)
     int slot = 0;
     {   // layers_dir.1^T (h part); layers_dir.0 is linear: dA = dG.  B operand copied (see nerf_bwd_kernel).
         f32x16 Bd[4];
@@ -411,17 +421,17 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
 // =========================================================================================
 // dU = dX (.) C with C = 30 cos(30 u) rebuilt from the saved (sign-encoded) X rows; leaves dU in X.  Nothing is stored here:
 // the first chain layer's mid slots write these rows (film_chain_layer), like every other layer's.
+// `cv`: the point's saved X_8 row, loaded by the caller at the top of the kernel (its latency then overlaps the first
+// weight stage's DMA and the head gradients instead of following them).
 template <int MB>
-__device__ __forceinline__ void film_bwd_first(const f32x16 (&dX)[8], f32x16 (&X)[8], const float* __restrict__ Xs, int64_t p,
-                                               int h) {
-    const f32x4* crow = reinterpret_cast<const f32x4*>(Xs + p * 256 + 4 * h);
+__device__ __forceinline__ void film_bwd_first(const f32x16 (&dX)[8], f32x16 (&X)[8], const f32x4 (&cv)[32]) {
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 cv = crow[m * 8 + rg * 2];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) X[m][4 * rg + q] = dsin30_from_saved(cv[q]) * dX[m][4 * rg + q];
+            const f32x4 c = dsin30_from_saved_x4(cv[m * 4 + rg]);
+            const f32x4 o = c * f32x4{dX[m][4 * rg + 0], dX[m][4 * rg + 1], dX[m][4 * rg + 2], dX[m][4 * rg + 3]};
+            X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
         }
 }
 
@@ -520,6 +530,12 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     const auto film_row = [&](int r) { return smem + kLdsFilm0 + ((8 - r) & 1) * kFilmRow; };       // FiLM row r's LDS slot
     const auto C = [&](int l) { return a.acts + (int64_t)(8 + 256 * l) * P; };    // saved X_l rows: C_l is rebuilt from them
     const auto dU = [&](int l) { return a.grads + (int64_t)(256 * l) * P; };
+    f32x4 ring[32];                                            // a layer's C quarters, loaded a K block or more ahead
+    {   // the first epilogue's rows (X_8) now, while the first weight stage is still on its way
+        const f32x4* crow = reinterpret_cast<const f32x4*>(C(8) + p * 256 + 4 * c.h);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) ring[j] = crow[(j / 4) * 8 + (j % 4) * 2];
+    }
 
     __syncthreads();
     {   // dX_8 = W_rgb^T d_pre_rgb (256 features)
@@ -535,10 +551,9 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    film_bwd_first<8>(acc, X, C(8), p, c.h);                                                     // hidden_layer_rgb: X = dU_8
+    film_bwd_first<8>(acc, X, ring);                                                             // hidden_layer_rgb: X = dU_8
     // Chain layer j multiplies by FiLM row j + 1 (slot (7 - j) & 1) and DMAs row j - what layer j - 1 multiplies by -
     // into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
-    f32x4 ring[32];                                            // the layer's C quarters, loaded a K block or more ahead
     film_chain_layer<32, true, true, false>(c, 3, ds, acc, X, ring, C(7), dU(7), dU(8), p, 0, 7, film_row(8));
 #pragma unroll 1
     for (int j = 6; j >= 1; --j)                                                                 // hidden_layers[5..0]

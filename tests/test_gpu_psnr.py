@@ -24,7 +24,9 @@ relative - about what separates two fp32 forward passes; a regime can only gate 
                                                                                       perturbed: 1e-4 / 4e-4 dB
   siren_nerf / film_siren_nerf   plain SGD 2e-4, all rays, 8 steps: Adam's first updates are m/sqrt(v) = +-1 per element
                    whatever the gradient's size, so only a step PROPORTIONAL to the gradient shows a gradient
-                   of the wrong magnitude in the next loss; the loss falls 6x / 18x in these 8 steps: gated at 1e-4
+                   of the wrong magnitude in the next loss; the loss falls 6x / 18x in these 8 steps.  Perturbed by 1e-6 the
+                   SirenNeRF run moves by 4e-6 per step (gated at 1e-4), the FiLM run - whose first step takes the loss from 0.286
+                   to 0.211 - by 2.5e-4 (gated at 2e-3)
 
   Adam at pi_GAN/train.py's 5e-5 is NOT such a regime: the loss rises 50 % over its first two steps, and that transient
   turns a 1e-7 perturbation into 6e-3 dB - fp32 vs fp64 on one host agreed to 1e-4 dB there, yet two hosts' CPUs landed
@@ -100,7 +102,7 @@ def test_tiny_nerf_fit_matches_the_cpu_loop_run_live():
 
 # fixture, loss gate (relative, every step), the fit must reach this fraction of its first loss
 REFERENCE_RUNS = [("fit_r03_siren_adam", 0.01, 0.2), ("fit_r03_film_adam", 0.01, 0.2),
-                  ("fit_r03_siren_sgd", 1e-4, 0.3), ("fit_r03_film_sgd", 1e-4, 0.3)]
+                  ("fit_r03_siren_sgd", 1e-4, 0.3), ("fit_r03_film_sgd", 2e-3, 0.3)]
 
 
 @pytest.mark.parametrize("name,rel_gate,must_reach", REFERENCE_RUNS)

@@ -269,7 +269,7 @@ def test_fit_trajectory_fixtures_are_reproduced_by_the_oracle_loop(golden):
         assert float(g["oracle_loop_max_rel_loss_diff"]) <= (1.0 if name.endswith("chaotic") else 1e-4)
         if not name.endswith("chaotic"):       # the hard regimes are quiet under a 1e-6 perturbation of the initial weights
             assert abs(float(g["perturbed_1e6_psnr"]) - float(g["heldout_psnr"])) <= 2e-3
-            assert float(g["perturbed_1e6_max_rel_loss_diff"]) <= 2e-3
+            assert float(g["perturbed_1e6_max_rel_loss_diff"]) <= 5e-3      # max |d loss| over the run / the SMALLEST loss
             assert g["losses"][-1] < 0.3 * g["losses"][0]
     g = golden("fit_r03_siren_sgd")
     scene = fit_ref.Scene(student="siren_nerf")
