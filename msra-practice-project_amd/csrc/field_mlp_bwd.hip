@@ -551,14 +551,27 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
+    MI_STAMP(a, 0);
     film_bwd_first<8>(acc, X, ring);                                                             // hidden_layer_rgb: X = dU_8
+    MI_STAMP(a, 1);
     // Chain layer j multiplies by FiLM row j + 1 (slot (7 - j) & 1) and DMAs row j - what layer j - 1 multiplies by -
     // into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
     film_chain_layer<32, true, true, false>(c, 3, ds, acc, X, ring, C(7), dU(7), dU(8), p, 0, 7, film_row(8));
+    MI_STAMP(a, 2);
 #pragma unroll 1
-    for (int j = 6; j >= 1; --j)                                                                 // hidden_layers[5..0]
+    for (int j = 6; j >= 1; --j) {                                                               // hidden_layers[5..0]
+#ifdef MI_PROFILE_STAMPS
+        if (j == 4 && a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;            // rows of layer j = 4: 32..64
+#endif
         film_chain_layer<32, false, true, false>(c, 0, 0.f, acc, X, ring, C(j), dU(j), dU(j + 1), p, (7 - j) & 1, j, film_row(j + 1));
+#ifdef MI_PROFILE_STAMPS
+        if (c.rowst) { MI_ROW_STAMP(c); }
+        c.rowst = nullptr;
+        if (threadIdx.x == 0 && a.stamps) a.stamps[(int64_t)blockIdx.x * 128 + 3 + (6 - j)] = __builtin_amdgcn_s_memtime();   // 3..8
+#endif
+    }
     film_chain_layer<0, false, false, true>(c, 0, 0.f, acc, X, ring, C(0), dU(0), dU(1), p, 1, 0, film_row(1));   // input_layer
+    MI_STAMP(a, 9);
 }
 
 // FiLM layer finishing for ONE image (group) g.  T[f][k] = sum_{p in g} dL/du[p][f] X[p][k] (tk = 256, or the 3

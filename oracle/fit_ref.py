@@ -20,7 +20,11 @@ class Scene:
     """`n_views` training views + one held-out view of a teacher tiny_nerf ("medium" density), res x res pixels;
     the student pair is of kind `student` (tiny_nerf: PE + ReLU, or siren_nerf: the sin(30 u) family)."""
 
-    def __init__(self, res=24, n_views=6, nc=16, nf=16, seed=100, student="tiny_nerf"):
+    def __init__(self, res=24, n_views=6, nc=16, nf=16, seed=100, student="tiny_nerf", images=None):
+        """`images` [n_views + 1, res*res, 3]: the teacher's views as rendered elsewhere (fixture fit_r03_scene.npz: the
+        build container's render).  The teacher is rendered by the oracle through the ill-conditioned hierarchical
+        resampling, so two hosts' CPUs paint a few rays differently (1e-4 of the loss): a trajectory recorded on one host
+        can only be compared with a run that fits the SAME pictures."""
         self.res, self.nc, self.nf, self.student = res, nc, nf, student
         self.focal = 1.3875 * res
         # FiLM students: one fixed FiLM row [9,512] (a single "image" of the mapping network's output, gamma ~ 1,
@@ -33,8 +37,11 @@ class Scene:
         self.poses = [synth.pose_degrees(4.0, float(a), -30.0) for a in angles]
         self.rays = [torch.from_numpy(R.rays_from_camera(res, res, self.focal, p)) for p in self.poses]
         imgs = []
+        if images is not None:
+            imgs = [torch.as_tensor(np.asarray(im), dtype=torch.float32) for im in images]
+            assert len(imgs) == n_views + 1 and tuple(imgs[0].shape) == (res * res, 3)
         with torch.no_grad():
-            for i, r in enumerate(self.rays):
+            for i, r in enumerate(self.rays if images is None else []):
                 t = R.render_rays(r, NEAR, FAR, teacher, teacher, 32, 64, synth.t_rand(res * res, 32, seed=7000 + i))
                 imgs.append(t.rgb_f)
         self.images = imgs                                    # [res*res, 3] each; the last one is held out

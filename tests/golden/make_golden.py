@@ -310,7 +310,8 @@ FIT_REGIMES = [  # name, student kind, optimiser, lr, steps (every step takes al
 def make_r03_fit(nr, nm, pm):
     """F10 fit_r03_*: the loop of nerf/train_nerf.py:124-176 run by the REFERENCE's own code on this container's CPU - its
     render_rays (nerf/render.py:106-147), its SirenNeRF / FilmSirenNeRF modules, torch.optim.Adam / SGD - on the synthetic
-    teacher scene of oracle/fit_ref.py (rays, teacher images, initial weights, per-step jitter: inputs), so that the GPU
+    teacher scene of oracle/fit_ref.py (rays, teacher images - stored as fit_r03_scene.npz, because another host's CPU renders
+    a few of their rays differently -, initial weights, per-step jitter: inputs), so that the GPU
     tests compare the HIP path's training trajectory with the reference's without re-running a 1-2 minute CPU fit per
     regime on the GPU box.  Stored: the loss of every step, the held-out view and its PSNR, and - to document the
     regime's own noise - the PSNR of the same run from initial weights perturbed by 1e-6 relative.  The oracle's own loop
@@ -339,6 +340,7 @@ def make_r03_fit(nr, nm, pm):
             held = nr.render_rays(scene.rays[-1], fit_ref.NEAR, fit_ref.FAR, models[0], models[1], scene.nc, scene.nf)
         return np.array(losses), held[3].numpy(), oref.psnr(held[3].numpy(), scene.images[-1].numpy())
 
+    save("fit_r03_scene", images=torch.stack(fit_ref.Scene().images))      # the teacher's seven views as rendered HERE
     for name, student, optimizer, lr0, steps in FIT_REGIMES:
         batch = 256 if name.endswith("chaotic") else 0
         scene = fit_ref.Scene(student=student)

@@ -109,7 +109,7 @@ REFERENCE_RUNS = [("fit_r03_siren_adam", 0.01, 0.2), ("fit_r03_film_adam", 0.01,
 def test_sin_family_fit_matches_the_reference_codes_own_trajectory(golden, name, rel_gate, must_reach):
     g = golden(name)
     student, optimizer, lr0, steps, batch = str(g["student"]), str(g["optimizer"]), float(g["lr0"]), int(g["steps"]), int(g["batch"])
-    scene = fit_ref.Scene(student=student)
+    scene = fit_ref.Scene(student=student, images=golden("fit_r03_scene")["images"])     # the pictures the reference run fitted
     assert synth.digest(scene.student_init[0]) == str(g["digest_c"]) and synth.digest(scene.student_init[1]) == str(g["digest_f"])
     ref_losses, ref_psnr = g["losses"], float(g["heldout_psnr"])
     hip_losses, hip_psnr, held = fit_hip(scene, steps, batch, lr0, optimizer)
@@ -140,7 +140,7 @@ def test_chaotic_siren_regime_is_recorded_as_a_diagnostic(golden):
     (forward, first gradients' signs, first Adam update) at 1e-5."""
     g = golden("fit_r03_siren_chaotic")
     steps, batch = int(g["steps"]), int(g["batch"])
-    scene = fit_ref.Scene(student="siren_nerf")
+    scene = fit_ref.Scene(student="siren_nerf", images=golden("fit_r03_scene")["images"])
     hip_losses, hip_psnr, _ = fit_hip(scene, steps, batch)
     rel = np.abs(np.array(hip_losses) - g["losses"]) / g["losses"]
     parity.record(case=f"teacher scene fit (siren_nerf, CHAOTIC regime) 24x24 16+16, {steps} adam steps (lr 5e-4) of {batch} rays",

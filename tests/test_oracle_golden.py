@@ -272,7 +272,7 @@ def test_fit_trajectory_fixtures_are_reproduced_by_the_oracle_loop(golden):
             assert float(g["perturbed_1e6_max_rel_loss_diff"]) <= 5e-3      # max |d loss| over the run / the SMALLEST loss
             assert g["losses"][-1] < 0.3 * g["losses"][0]
     g = golden("fit_r03_siren_sgd")
-    scene = fit_ref.Scene(student="siren_nerf")
+    scene = fit_ref.Scene(student="siren_nerf", images=golden("fit_r03_scene")["images"])    # the pictures the reference run fitted
     assert synth.digest(scene.student_init[0]) == str(g["digest_c"])
     losses, _, _ = fit_ref.fit_cpu(scene, 2, 0, lr0=float(g["lr0"]), optimizer="sgd")
     assert np.abs(np.array(losses) - g["losses"][:2]).max() <= 1e-5 * g["losses"][0]
