@@ -232,8 +232,11 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         }
         if constexpr (!DEFER) drow[m * 8 + rg * 2] = o;
     };
-    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !SCALED>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
-                                                                       NoHook{}, bsel, acc, pre, post, mid);
+    // a layer that stores its own dA rows (the chain's last one: there is no next layer to do it) runs its last K block
+    // m-major, so the 32 row stores of the epilogue are spread over 128 MFMAs instead of bursting out of the last 32
+    // (stamped profile, round 3: the FiLM chain's last layer took 89.5 k cycles where the others take 76-78 k)
+    mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !SCALED, !DEFER>(c, issue_slot < 0 ? aux_slot : issue_slot, next_film_layer,
+                                                                               NoHook{}, bsel, acc, pre, post, mid);
 }
 
 // =========================================================================================
@@ -504,7 +507,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, f32
         if constexpr (LAST) drow[m * 8 + rg * 2] = o;
     };
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
-    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true, !SCALED>(c, issue_slot, next_film_layer, NoHook{}, sel_x, acc, pre, post, mid);
+    mma_layer_fn<8, 8, 0, 0, NEXT_BLOCK, FILM_NEXT, true, !SCALED, LAST>(c, issue_slot, next_film_layer, NoHook{}, sel_x, acc, pre, post, mid);
 }
 
 template <bool USE_DIR>
@@ -556,12 +559,21 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     MI_STAMP(a, 1);
     // Chain layer j multiplies by FiLM row j + 1 (slot (7 - j) & 1) and DMAs row j - what layer j - 1 multiplies by -
     // into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
+#if defined(MI_PROFILE_STAMPS) && defined(MI_STAMP_LAYER) && MI_STAMP_LAYER == 7
+    if (a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;                          // rows of layer 7: 32..64
+#endif
     film_chain_layer<32, true, true, false>(c, 3, ds, acc, X, ring, C(7), dU(7), dU(8), p, 0, 7, film_row(8));
+#if defined(MI_PROFILE_STAMPS) && defined(MI_STAMP_LAYER) && MI_STAMP_LAYER == 7
+    if (c.rowst) { MI_ROW_STAMP(c); }
+    c.rowst = nullptr;
+#endif
     MI_STAMP(a, 2);
 #pragma unroll 1
     for (int j = 6; j >= 1; --j) {                                                               // hidden_layers[5..0]
 #ifdef MI_PROFILE_STAMPS
+#if !defined(MI_STAMP_LAYER) || MI_STAMP_LAYER != 7
         if (j == 4 && a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;            // rows of layer j = 4: 32..64
+#endif
 #endif
         film_chain_layer<32, false, true, false>(c, 0, 0.f, acc, X, ring, C(j), dU(j), dU(j + 1), p, (7 - j) & 1, j, film_row(j + 1));
 #ifdef MI_PROFILE_STAMPS
