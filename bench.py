@@ -436,7 +436,7 @@ def main():
     mean_flops = sum(launch_flops) / len(launch_flops)
     achieved = mean_flops / (mean_ms * 1e-3) / 1e12
     # HBM bytes per launch: not measurable from inside the process; taken from the committed rocprofv3 PMC
-    # passes of this same command (profiles/r01_pmc_nerf_fwd.json: WRITE_SIZE + 2 x FETCH_SIZE per the gfx950
+    # passes of this same command (profiles/rNN_pmc_nerf_fwd.json, the newest round's: WRITE_SIZE + 2 x FETCH_SIZE per the gfx950
     # correction of MI355X_MICROARCH.md, per point) scaled to the mean points per launch.  null if absent.
     traffic = None
     pmc_path = newest_profile("pmc_nerf_fwd.json")

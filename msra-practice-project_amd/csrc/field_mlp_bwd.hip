@@ -591,34 +591,53 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
 //   dW[f][col0+k]  (+)= gamma[f] T[f][k]                       (+= for g > 0: images are summed in order)
 //   d gamma_g[f]   (+)= sum_k W[f][col0+k] T[f][k]  (+ b[f] s[f] with the bias part: A = W x + b)
 //   d beta_g[f]      = s[f];   db[f] (+)= gamma[f] s[f]        (bias part only)
-__global__ __launch_bounds__(256) void film_finish_kernel(const float* __restrict__ T, int tk, const float* __restrict__ s,
-                                                          const float* __restrict__ W, int w_ld, int col0,
-                                                          const float* __restrict__ b, const float* __restrict__ film_row,
-                                                          int first_group, int bias_part, float* __restrict__ dW,
-                                                          float* __restrict__ db, float* __restrict__ dfilm_row) {
+constexpr int kMaxFinishJobs = 10;          // an image's nine FiLM layers + the dir columns of hidden_layer_rgb
+struct FinishJob {
+    const float* T; const float* s; const float* W; const float* b; const float* film_row;
+    float* dW; float* db; float* dfilm_row;
+    int tk, w_ld, col0, bias_part;
+};
+struct FinishBatch { FinishJob job[kMaxFinishJobs]; int first_group; };
+
+// grid = (256 rows, jobs): every finishing job of one image in ONE launch (round 2: ten launches of 4.6 us per image,
+// 320 per C4 step).  A job that adds to a d gamma another job of the same launch WRITES (hidden_layer_rgb's dir columns
+// after its h columns: bias_part = 0) runs in the same workgroup right after it - see launch_field_backward.
+__global__ __launch_bounds__(256) void film_finish_kernel(FinishBatch fb) {
     __shared__ float red[4];
     const int f = blockIdx.x, k = threadIdx.x;
-    const float gamma = film_row[f];
-    float dot = 0.f;
-    if (k < tk) {
-        const float t = T[f * tk + k];
-        float* w = dW + (int64_t)f * w_ld + col0 + k;
-        *w = first_group ? gamma * t : *w + gamma * t;
-        dot = W[(int64_t)f * w_ld + col0 + k] * t;
-    }
-    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
-    if ((k & 63) == 0) red[k >> 6] = dot;
-    __syncthreads();
-    if (k == 0) {
-        float dg = ((red[0] + red[1]) + red[2]) + red[3];
-        if (bias_part) {
-            dg += b[f] * s[f];
-            dfilm_row[f] = dg;
-            dfilm_row[256 + f] = s[f];
-            db[f] = first_group ? gamma * s[f] : db[f] + gamma * s[f];
-        } else {
-            dfilm_row[f] += dg;
+    const int first_group = fb.first_group;
+    // blockIdx.y indexes the jobs with a bias part; a job without one (it ADDS to the d gamma row of the job before it
+    // in the table) is chained behind its predecessor here, so the two never race
+    int j = 0;
+    for (int seen = -1; j < kMaxFinishJobs; ++j)
+        if (fb.job[j].T && fb.job[j].bias_part && ++seen == (int)blockIdx.y) break;
+    if (j >= kMaxFinishJobs) return;
+    for (; j < kMaxFinishJobs && fb.job[j].T; ++j) {
+        const FinishJob& q = fb.job[j];
+        const float gamma = q.film_row[f];
+        float dot = 0.f;
+        if (k < q.tk) {
+            const float t = q.T[f * q.tk + k];
+            float* w = q.dW + (int64_t)f * q.w_ld + q.col0 + k;
+            *w = first_group ? gamma * t : *w + gamma * t;
+            dot = q.W[(int64_t)f * q.w_ld + q.col0 + k] * t;
         }
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        __syncthreads();                                   // red[] of the previous job of this chain has been consumed
+        if ((k & 63) == 0) red[k >> 6] = dot;
+        __syncthreads();
+        if (k == 0) {
+            float dg = ((red[0] + red[1]) + red[2]) + red[3];
+            if (q.bias_part) {
+                dg += q.b[f] * q.s[f];
+                q.dfilm_row[f] = dg;
+                q.dfilm_row[256 + f] = q.s[f];
+                q.db[f] = first_group ? gamma * q.s[f] : q.db[f] + gamma * q.s[f];
+            } else {
+                q.dfilm_row[f] += dg;
+            }
+        }
+        if (j + 1 < kMaxFinishJobs && fb.job[j + 1].T && fb.job[j + 1].bias_part) break;     // the next job is another chain's head
     }
 }
 
@@ -1208,15 +1227,19 @@ int launch_field_backward(int kind, const float* packed_bwd, const float* acts, 
             }
             BwdBatcher bb{ppg, partial, 0, stream};
             if ((rc = jobs(bb))) return rc;
+            FinishBatch fb{};
+            int n_fin = 0, n_heads = 0;
+            fb.first_group = first;
             const auto finish = [&](const float* t, int tk, const float* sg, int l, int wp, int w_ld, int col0, int bias_part) {
-                hipLaunchKernelGGL(film_finish_kernel, dim3(256), dim3(256), 0, stream, t, tk, sg, params[2 * wp], w_ld, col0,
-                                   params[2 * wp + 1], frow + l * kFilmRow, first, bias_part, gp[2 * wp], gp[2 * wp + 1],
-                                   dfrow + l * kFilmRow);
+                fb.job[n_fin++] = FinishJob{t, sg, params[2 * wp], params[2 * wp + 1], frow + l * kFilmRow, gp[2 * wp], gp[2 * wp + 1],
+                                            dfrow + l * kFilmRow, tk, w_ld, col0, bias_part};
+                n_heads += bias_part;
             };
             finish(T3_0, 3, s0, 0, 0, 3, 0, 1);                               // input_layer: FiLM layer 0, parameter pair 0
             for (int l = 1; l <= 7; ++l) finish(Tl(l), 256, sl(l), l, l, 256, 0, 1);      // hidden_layers[l-1]: pair l
             finish(Tl(8), 256, sl(8), 8, 9, ld9, 0, 1);                       // hidden_layer_rgb: FiLM layer 8, pair 9: [X_7 | dir]
-            if (use_dir) finish(T3_8, 3, sl(8), 8, 9, 259, 256, 0);
+            if (use_dir) finish(T3_8, 3, sl(8), 8, 9, 259, 256, 0);           // ... its dir columns: chained behind the job above
+            hipLaunchKernelGGL(film_finish_kernel, dim3(256, n_heads), dim3(256), 0, stream, fb);
         }
         if ((rc = check_launch("film_finish_kernel"))) return rc;
         // heads: sigma (param pair 8) on X_7, rgb (pair 10) on X_8 - no FiLM in between, all images at once

@@ -36,3 +36,20 @@ def test_one_rank_rccl_group_runs_every_collective_of_the_product():
     assert r.returncode == 0, log[-4000:]
     assert "backend nccl" in r.stdout and "rccl one-rank: OK" in r.stdout
     assert r.stdout.count("PASS bit-equal") == 3
+
+
+@pytest.mark.timeout(600)
+def test_bench_force_collective_runs_the_headline_frame_through_a_one_rank_rccl_group():
+    """`python bench.py --force-collective` (N = 1): the timed 800x800 frame is assembled by RCCL's all_gather_into_tensor
+    in a one-rank nccl group, and the line carries the `collective` object the N > 1 lines carry - the code path of the
+    driver's 8-GPU scaling run, exercised where only one GPU exists."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-collective", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-frame64", "--no-train"], capture_output=True, text=True, timeout=500,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = line["collective"]
+    assert c["backend"] == "nccl" and c["n_ranks_seen"] == 1 and c["frames"] == 1
+    assert c["allgather_bytes_per_rank"] == 800 * 800 * 5 * 4 and c["per_rank_allgather_ms"][0] > 0
+    assert line["n_gpus"] == 1 and line["value"] > 1e5
