@@ -110,6 +110,25 @@ int mi_sample_fine(int64_t n, float near_, float far_, int n_coarse, int n_fine,
                    const float* u_lin, const float* z_coarse, const float* weights, float* z_samples,
                    float* z_fine, void* stream);
 
+/* The same, also returning where every input element went: pos [n, Nc+Nf] int32, pos[e] = index in z_fine of
+ * z_coarse[e] (e < Nc) or of z_samples[e - Nc].  What a renderer needs to evaluate ONE field shared by both passes
+ * (pi_GAN/modules.py:160-161 passes the same model twice; nerf/train_nerf.py:91,94 with use_fine_model off) at the Nf new
+ * depths only: the fine pass of nerf/render.py:143-144 re-evaluates the Nc coarse points with the same field. */
+int mi_sample_fine_pos(int64_t n, float near_, float far_, int n_coarse, int n_fine, const float* z_lin,
+                       const float* u_lin, const float* z_coarse, const float* weights, float* z_samples,
+                       float* z_fine, int* pos, void* stream);
+
+/* raw_fine [n,Nc+Nf,4] in sorted order out of the coarse pass's raw_coarse [n,Nc,4] and raw_samples [n,Nf,4] (the field at
+ * z_samples): raw_fine[pos[e]] = e < Nc ? raw_coarse[e] : raw_samples[e - Nc].  Replaces the second field call of
+ * nerf/render.py:144 when both passes share one field; bit-identical to it. */
+int mi_merge_raw(int64_t n, int n_coarse, int n_fine, const float* raw_coarse, const float* raw_samples, const int* pos,
+                 float* raw_fine, void* stream);
+
+/* The transpose of mi_merge_raw for the backward pass: g_raw_coarse[e] (+)= g_raw_fine[pos[e]] (+= when
+ * accumulate_coarse: onto the coarse outputs' own gradient), g_raw_samples[i] = g_raw_fine[pos[Nc + i]]. */
+int mi_split_grad(int64_t n, int n_coarse, int n_fine, const float* g_raw_fine, const int* pos, float* g_raw_coarse,
+                  int accumulate_coarse, float* g_raw_samples, void* stream);
+
 /* sample_pdf as a free-standing function (nerf/render.py:27-56; star-imported by the reference's scripts):
  * bins [n,n_bins], weights [n,n_bins-1] -> samples [n,n_samples]; u_lin [n_samples] optional table as above. */
 int mi_sample_pdf(int64_t n, int n_bins, int n_samples, const float* bins, const float* weights,
@@ -121,13 +140,17 @@ int mi_sample_pdf(int64_t n, int n_bins, int n_samples, const float* bins, const
  *   rays [n,2,3]; n = n_groups*rays_per_group; film tables as in mi_field_eval_rays
  *   outs: rgb_c[n,3] depth_c[n] acc_c[n] rgb_f[n,3] depth_f[n] acc_f[n]
  *   seed, ray0: as in mi_sample_coarse (used when t_rand is NULL)
- *   workspace: mi_render_workspace_bytes(n, Nc, Nf) bytes */
+ *   workspace: mi_render_workspace_bytes(n, Nc, Nf) bytes; workspace_bytes = what the caller really provided.
+ *   When both passes share one field (same kind, same packed pointer) and the workspace also holds
+ *   mi_render_shared_field_extra_bytes(n, Nc, Nf) more, the fine pass evaluates the Nf new depths only (mi_merge_raw);
+ *   with Nf = 0 it aliases the coarse outputs.  Results are bit-identical either way. */
 int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine);
+int64_t mi_render_shared_field_extra_bytes(int64_t n, int n_coarse, int n_fine);
 int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, const float* packed_fine,
                    const float* film, const float* rays, int64_t n_groups, int64_t rays_per_group,
                    float near_, float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin,
                    const float* t_rand, uint64_t seed, uint64_t ray0, float* rgb_c, float* depth_c, float* acc_c,
-                   float* rgb_f, float* depth_f, float* acc_f, void* workspace, void* stream);
+                   float* rgb_f, float* depth_f, float* acc_f, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- training: what autograd does for the reference (train_nerf.py:151-168) ------------------ */
 

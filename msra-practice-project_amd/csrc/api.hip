@@ -72,7 +72,7 @@ using namespace mi;
 
 extern "C" {
 
-int mi_abi_version(void) { return 2; }
+int mi_abi_version(void) { return 3; }
 const char* mi_last_error(void) { return g_err; }
 
 int mi_field_num_params(int kind) { return bad_kind(kind) ? MI_EINVAL : 2 * kNumLayers[kind]; }
@@ -135,8 +135,38 @@ int mi_sample_fine(int64_t n, float near_, float far_, int n_coarse, int n_fine,
         set_error("mi_sample_fine: bad arguments (need Nc >= 3)");
         return MI_EINVAL;
     }
-    return launch_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_coarse, weights, z_samples, z_fine,
+    return launch_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_coarse, weights, z_samples, z_fine, nullptr,
                               (hipStream_t)stream);
+}
+
+int mi_sample_fine_pos(int64_t n, float near_, float far_, int n_coarse, int n_fine, const float* z_lin,
+                       const float* u_lin, const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
+                       int* pos, void* stream) {
+    if (n < 0 || n_coarse < 3 || n_fine < 0 || !z_coarse || !weights || !z_fine || !pos) {
+        set_error("mi_sample_fine_pos: bad arguments (need Nc >= 3 and a pos table)");
+        return MI_EINVAL;
+    }
+    return launch_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_coarse, weights, z_samples, z_fine, pos,
+                              (hipStream_t)stream);
+}
+
+int mi_merge_raw(int64_t n, int n_coarse, int n_fine, const float* raw_coarse, const float* raw_samples, const int* pos,
+                 float* raw_fine, void* stream) {
+    if (n < 0 || n_coarse < 1 || n_fine < 0 || !raw_coarse || (n_fine > 0 && !raw_samples) || !pos || !raw_fine) {
+        set_error("mi_merge_raw: bad arguments");
+        return MI_EINVAL;
+    }
+    return launch_merge_raw(n, n_coarse, n_fine, raw_coarse, raw_samples, pos, raw_fine, (hipStream_t)stream);
+}
+
+int mi_split_grad(int64_t n, int n_coarse, int n_fine, const float* g_raw_fine, const int* pos, float* g_raw_coarse,
+                  int accumulate_coarse, float* g_raw_samples, void* stream) {
+    if (n < 0 || n_coarse < 1 || n_fine < 0 || !g_raw_fine || !pos || !g_raw_coarse || (n_fine > 0 && !g_raw_samples)) {
+        set_error("mi_split_grad: bad arguments");
+        return MI_EINVAL;
+    }
+    return launch_split_grad(n, n_coarse, n_fine, g_raw_fine, pos, g_raw_coarse, accumulate_coarse, g_raw_samples,
+                             (hipStream_t)stream);
 }
 
 int mi_sample_pdf(int64_t n, int n_bins, int n_samples, const float* bins, const float* weights, const float* u_lin,
@@ -157,17 +187,31 @@ int64_t mi_render_workspace_bytes(int64_t n, int n_coarse, int n_fine) {
     return f * (int64_t)sizeof(float);
 }
 
+int64_t mi_render_shared_field_extra_bytes(int64_t n, int n_coarse, int n_fine) {
+    // z_samples[n,Nf] raw_samples[n,Nf,4] pos[n,Nc+Nf] behind the regions of mi_render_workspace_bytes
+    int64_t f = 0;
+    auto add = [&](int64_t x) { f += (x + 63) / 64 * 64; };
+    add(n * n_fine); add(n * n_fine * 4); add(n * ((int64_t)n_coarse + n_fine));
+    return f * (int64_t)sizeof(float);
+}
+
 int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, const float* packed_fine,
                    const float* film, const float* rays, int64_t n_groups, int64_t rays_per_group, float near_,
                    float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin, const float* t_rand,
                    uint64_t seed, uint64_t ray0, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f,
-                   float* depth_f, float* acc_f, void* workspace, void* stream) {
+                   float* depth_f, float* acc_f, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!workspace || !rays || !rgb_c || !depth_c || !acc_c || !rgb_f || !depth_f || !acc_f) {
         set_error("mi_render_rays: null pointer argument");
         return MI_EINVAL;
     }
     const int64_t n = n_groups * rays_per_group;
     const int S = n_coarse + n_fine;
+    const int64_t base_bytes = mi_render_workspace_bytes(n, n_coarse, n_fine);
+    if (workspace_bytes < base_bytes) {
+        set_error("mi_render_rays: workspace of %lld bytes, mi_render_workspace_bytes says %lld", (long long)workspace_bytes,
+                  (long long)base_bytes);
+        return MI_EINVAL;
+    }
     float* ws = (float*)workspace;
     auto take = [&](int64_t x) { float* p = ws; ws += (x + 63) / 64 * 64; return p; };
     float* z_c = take(n * n_coarse);
@@ -194,6 +238,22 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
             return MI_EHIP;
         }
         return MI_OK;
+    }
+    if (kind_fine == kind_coarse && packed_fine == packed_coarse &&
+        workspace_bytes >= base_bytes + mi_render_shared_field_extra_bytes(n, n_coarse, n_fine)) {
+        // One field for both passes: Nc of the fine pass's Nc + Nf points are the coarse pass's points - evaluate the Nf
+        // new ones only and merge (render_stages.hip: merge_raw_kernel).  Needs the extra workspace regions; a caller
+        // that did not provide them gets the plain path below (same results).
+        float* z_s = take(n * n_fine);
+        float* raw_s = take(n * (int64_t)n_fine * 4);
+        int* pos = (int*)take(n * (int64_t)S);
+        if ((rc = mi_sample_fine_pos(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_c, w_c, z_s, z_f, pos, stream))) return rc;
+        if (g_mlp_ev[2]) (void)hipEventRecord(g_mlp_ev[2], hs);
+        if ((rc = mi_field_eval_rays(kind_fine, packed_fine, film, rays, z_s, n_groups, rays_per_group, n_fine, raw_s, stream)))
+            return rc;
+        if (g_mlp_ev[3]) (void)hipEventRecord(g_mlp_ev[3], hs);
+        if ((rc = mi_merge_raw(n, n_coarse, n_fine, raw_c, raw_s, pos, raw_f, stream))) return rc;
+        return mi_composite(n, S, raw_f, z_f, rays, rgb_f, depth_f, acc_f, nullptr, stream);
     }
     if ((rc = mi_sample_fine(n, near_, far_, n_coarse, n_fine, z_lin, u_lin, z_c, w_c, nullptr, z_f, stream))) return rc;
     if (g_mlp_ev[2]) (void)hipEventRecord(g_mlp_ev[2], hs);

@@ -108,7 +108,11 @@ int launch_adam_step(int n_fields, const int* kinds, const int* n_params, float*
 int launch_sample_pdf(int64_t n, int nb, int ns, const float* bins, const float* weights, const float* u_lin, float* out,
                       hipStream_t stream);
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,
-                       const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
+                       const float* z_coarse, const float* weights, float* z_samples, float* z_fine, int* pos,
                        hipStream_t stream);
+int launch_merge_raw(int64_t n, int nc, int nf, const float* raw_c, const float* raw_s, const int* pos, float* raw_f,
+                     hipStream_t stream);
+int launch_split_grad(int64_t n, int nc, int nf, const float* g_f, const int* pos, float* g_c, int accumulate_coarse,
+                      float* g_s, hipStream_t stream);
 
 }  // namespace mi

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
                                                           const float* __restrict__ u_lin,
                                                           const float* __restrict__ z_coarse,
                                                           const float* __restrict__ weights,
-                                                          float* __restrict__ z_samples, float* __restrict__ z_fine) {
+                                                          float* __restrict__ z_samples, float* __restrict__ z_fine,
+                                                          int* __restrict__ pos) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int S = nc + nf;
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
                     if (coarse ? o < v : o <= v) lo_i = mid + 1; else hi_i = mid;
                 }
                 zout[(coarse ? e : e - nc) + lo_i] = v;
+                if (pos) pos[ray * S + e] = (coarse ? e : e - nc) + lo_i;
             }
         } else {
             for (int e0 = lane; e0 < S; e0 += 256) {                 // up to four elements per sweep over the list
@@ -384,7 +386,10 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(int64_t n, float near_
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (e0 + 64 * k < S) zout[rank[k]] = zall[e0 + 64 * k];
+                    if (e0 + 64 * k < S) {
+                        zout[rank[k]] = zall[e0 + 64 * k];
+                        if (pos) pos[ray * S + e0 + 64 * k] = rank[k];
+                    }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -506,8 +511,68 @@ int launch_sample_pdf(int64_t n, int nb, int ns, const float* bins, const float*
     return check_launch("sample_pdf");
 }
 
+// ---------------------------------------------------------------------------------------
+// One field for both passes (pi_GAN renders with coarse_model is fine_model, pi_GAN/modules.py:160-161; nerf with
+// use_fine_model off, nerf/train_nerf.py:91,94): the fine pass of render_rays (render.py:143-144) evaluates the field at
+// sort(cat(z_coarse, z_samples)) - and Nc of those Nc + Nf points are the very points the coarse pass evaluated, with the
+// same field: identical inputs, identical outputs.  The renderer then evaluates the Nf NEW points only and puts the
+// two sets of raw values into the sorted order with the positions the merge computed (`pos` of sample_fine_kernel:
+// pos[e] = index in z_fine of input element e, e < Nc coarse, else sample e - Nc).  Generalises the Nf = 0 alias of
+// SURVEY.md 8d C2; bit-identical to evaluating all Nc + Nf points because a point's value does not depend on which
+// launch or lane computed it.
+//   merge_raw:  raw_f[pos[e]] = e < Nc ? raw_c[e] : raw_s[e - Nc]
+//   split_grad: the transpose, for the backward pass: g_c[e] (+)= g_f[pos[e]], g_s[i] = g_f[pos[Nc + i]]
+// thread per (ray, element); float4 per point.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_raw_kernel(int64_t n, int nc, int nf, const float4* __restrict__ raw_c,
+                                                        const float4* __restrict__ raw_s, const int* __restrict__ pos,
+                                                        float4* __restrict__ raw_f) {
+    const int S = nc + nf;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * S) return;
+    const int64_t ray = i / S;
+    const int e = (int)(i - ray * S);
+    raw_f[ray * S + pos[i]] = e < nc ? raw_c[ray * nc + e] : raw_s[ray * nf + (e - nc)];
+}
+
+__global__ __launch_bounds__(256) void split_grad_kernel(int64_t n, int nc, int nf, const float4* __restrict__ g_f,
+                                                         const int* __restrict__ pos, float4* __restrict__ g_c,
+                                                         int accumulate_coarse, float4* __restrict__ g_s) {
+    const int S = nc + nf;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * S) return;
+    const int64_t ray = i / S;
+    const int e = (int)(i - ray * S);
+    const float4 g = g_f[ray * S + pos[i]];
+    if (e < nc) {
+        float4* d = g_c + ray * nc + e;
+        if (accumulate_coarse) { const float4 o = *d; *d = make_float4(o.x + g.x, o.y + g.y, o.z + g.z, o.w + g.w); }
+        else *d = g;
+    } else {
+        g_s[ray * nf + (e - nc)] = g;
+    }
+}
+
+int launch_merge_raw(int64_t n, int nc, int nf, const float* raw_c, const float* raw_s, const int* pos, float* raw_f,
+                     hipStream_t stream) {
+    const int64_t total = n * (nc + nf);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(merge_raw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, nc, nf,
+                       (const float4*)raw_c, (const float4*)raw_s, pos, (float4*)raw_f);
+    return check_launch("merge_raw");
+}
+
+int launch_split_grad(int64_t n, int nc, int nf, const float* g_f, const int* pos, float* g_c, int accumulate_coarse,
+                      float* g_s, hipStream_t stream) {
+    const int64_t total = n * (nc + nf);
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(split_grad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, n, nc, nf,
+                       (const float4*)g_f, pos, (float4*)g_c, accumulate_coarse, (float4*)g_s);
+    return check_launch("split_grad");
+}
+
 int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const float* z_lin, const float* u_lin,
-                       const float* z_coarse, const float* weights, float* z_samples, float* z_fine,
+                       const float* z_coarse, const float* weights, float* z_samples, float* z_fine, int* pos,
                        hipStream_t stream) {
     if (n <= 0) return 0;
     const size_t lds = (size_t)4 * (2 * nc + 2 * (nc + nf)) * sizeof(float);
@@ -515,7 +580,7 @@ int launch_sample_fine(int64_t n, float near_, float far_, int nc, int nf, const
     int64_t blocks = (n + 3) / 4;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(sample_fine_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, n, near_, far_, nc, nf,
-                       z_lin, u_lin, z_coarse, weights, z_samples, z_fine);
+                       z_lin, u_lin, z_coarse, weights, z_samples, z_fine, pos);
     return check_launch("sample_fine");
 }
 

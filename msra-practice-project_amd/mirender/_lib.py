@@ -37,6 +37,9 @@ SIGNATURES = {
     "mi_sample_coarse": (_int, [_i64, _f32, _f32, _int, _vp, _vp, _u64, _u64, _vp, _vp]),
     "mi_composite": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_sample_fine": (_int, [_i64, _f32, _f32, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_sample_fine_pos": (_int, [_i64, _f32, _f32, _int, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_merge_raw": (_int, [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
+    "mi_split_grad": (_int, [_i64, _int, _int, _vp, _vp, _vp, _int, _vp, _vp]),
     "mi_sample_pdf": (_int, [_i64, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "mi_image_metrics_workspace_floats": (_i64, [_int, _int, _int, _int]),
     "mi_image_metrics": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _int, _vp, _vp, _vp]),
@@ -48,8 +51,9 @@ SIGNATURES = {
                             ctypes.POINTER(_vp), ctypes.POINTER(_i64), _f32, _f32, _f32, _f32, _f32, _f32,
                             ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp]),
     "mi_render_workspace_bytes": (_i64, [_i64, _int, _int]),
+    "mi_render_shared_field_extra_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
-                              _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                              _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mi_composite_bwd": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_field_packed_bwd_floats": (_i64, [_int]),
     "mi_field_pack_bwd": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),

@@ -228,28 +228,52 @@ def _composite_bwd(raw, z, rays, g_rgb, g_depth, g_acc):
 
 
 class _RenderRaysFn(torch.autograd.Function):
+    """render_rays with autograd.  Two shapes:
+
+    * two fields (nerf's coarse / fine pair): coarse pass, resampling, fine pass over all Nc + Nf depths;
+    * ONE field for both passes (pi_GAN: `render_image(..., model, model, ...)`, pi_GAN/modules.py:160-161; nerf with
+      use_fine_model off, train_nerf.py:91,94): Nc of the fine pass's Nc + Nf points are the coarse pass's points, evaluated by
+      the same field - identical inputs, identical outputs (the reference evaluates them twice, render.py:135,144).  The
+      field runs on the Nf NEW depths only, `mi_merge_raw` puts both sets of raw values into the sorted order, and in
+      backward `mi_split_grad` hands the fine composite's gradient back to the two point sets: the coarse points get the
+      sum of what the coarse outputs and the fine outputs send them, and each set goes through the field's backward once.
+      48 -> 36 field evaluations per ray forward at 12+24 (pi_GAN C4), 120 -> 108 evaluation-equivalents per training step;
+      the outputs are bit-identical to evaluating all Nc + Nf points (tests/test_gpu_shared_field.py), the gradients equal
+      up to the order of two partial sums."""
+
     @staticmethod
     def forward(ctx, pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed, ray0, *params):
         dev = pf_c.device
         n = rays.shape[0]
+        shared = pf_c is pf_f
         z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed, ray0=ray0)
-        # the coarse pass often gets no gradient at all (pi_GAN trains through rgb_fine only): keep its layer inputs
-        # only when they are small; the fine pass may keep as many ranges as half the free HBM holds
-        raw_c, ctx.acts_c = _forward_pass(pf_c, rays, z_c, film, SAVE_COARSE_BYTES, all_or_nothing=True)
+        # two fields: the coarse pass often gets no gradient at all and keeps its layer inputs only when they are small.
+        # One field: its points always take part in backward (through the fine composite): kept like the fine pass's
+        raw_c, ctx.acts_c = _forward_pass(pf_c, rays, z_c, film, SAVE_FINE_BYTES if shared else SAVE_COARSE_BYTES,
+                                          all_or_nothing=not shared)
         rgb_c, depth_c, acc_c, w_c = ops.composite(raw_c, z_c, rays)
-        z_f = ops.sample_fine(z_c, w_c, near, far, nf)
-        raw_f, ctx.acts_f = _forward_pass(pf_f, rays, z_f, film, SAVE_FINE_BYTES)
+        empty = torch.empty(0, device=dev)
+        z_s = raw_s = pos = empty
+        if not shared:
+            z_f = ops.sample_fine(z_c, w_c, near, far, nf)
+            raw_f, ctx.acts_f = _forward_pass(pf_f, rays, z_f, film, SAVE_FINE_BYTES)
+        elif nf > 0:
+            z_f, z_s, pos = ops.sample_fine_pos(z_c, w_c, near, far, nf)
+            raw_s, ctx.acts_f = _forward_pass(pf_f, rays, z_s, film, SAVE_FINE_BYTES)        # the Nf new depths only
+            raw_f = ops.merge_raw(raw_c, raw_s, pos)
+        else:                                   # Nf = 0: sort(z_coarse) is z_coarse, the fine pass IS the coarse pass
+            z_f, raw_f, ctx.acts_f = z_c, raw_c, {}
         rgb_f, depth_f, acc_f, _ = ops.composite(raw_f, z_f, rays, want_weights=False)
         ctx.pf_c, ctx.pf_f, ctx.film = pf_c, pf_f, None if film is None else film.detach()
         ctx.versions = (pf_c.versions(), pf_f.versions())
-        ctx.n_c = len(pf_c.params)
-        ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f)
+        ctx.n_c, ctx.shared, ctx.nc, ctx.nf = len(pf_c.params), shared, nc, nf
+        ctx.save_for_backward(rays, z_c, raw_c, z_f, raw_f, z_s, raw_s, pos)
         ctx.set_materialize_grads(False)
         return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f
 
     @staticmethod
     def backward(ctx, g_rgb_c, g_depth_c, g_acc_c, g_rgb_f, g_depth_f, g_acc_f):
-        rays, z_c, raw_c, z_f, raw_f = ctx.saved_tensors
+        rays, z_c, raw_c, z_f, raw_f, z_s, raw_s, pos = ctx.saved_tensors
         pf_c, pf_f = ctx.pf_c, ctx.pf_f
         if (pf_c.versions(), pf_f.versions()) != ctx.versions:
             # backward re-reads the live weights (transposed stream, recomputed ranges) while raw and the kept layer
@@ -257,16 +281,32 @@ class _RenderRaysFn(torch.autograd.Function):
             # PyTorch raises for its own saved tensors in this situation; so do we.
             raise RuntimeError("render_rays backward: a field parameter was modified in place (or replaced) after the "
                                "forward pass that this backward belongs to")
-        same = pf_c is pf_f
         grads_c = grads_f = gfilm_c = gfilm_f = None
-        if any(g is not None for g in (g_rgb_c, g_depth_c, g_acc_c)):
-            g_raw = _composite_bwd(raw_c, z_c, rays, g_rgb_c, g_depth_c, g_acc_c)
-            grads_c, gfilm_c = _field_backward(pf_c, rays, z_c, raw_c, g_raw, ctx.film, ctx.acts_c)
-        if any(g is not None for g in (g_rgb_f, g_depth_f, g_acc_f)):
-            g_raw = _composite_bwd(raw_f, z_f, rays, g_rgb_f, g_depth_f, g_acc_f)
-            grads_f, gfilm_f = _field_backward(pf_f, rays, z_f, raw_f, g_raw, ctx.film, ctx.acts_f)
+        want_c = any(g is not None for g in (g_rgb_c, g_depth_c, g_acc_c))
+        want_f = any(g is not None for g in (g_rgb_f, g_depth_f, g_acc_f))
+        if not ctx.shared:
+            if want_c:
+                g_raw = _composite_bwd(raw_c, z_c, rays, g_rgb_c, g_depth_c, g_acc_c)
+                grads_c, gfilm_c = _field_backward(pf_c, rays, z_c, raw_c, g_raw, ctx.film, ctx.acts_c)
+            if want_f:
+                g_raw = _composite_bwd(raw_f, z_f, rays, g_rgb_f, g_depth_f, g_acc_f)
+                grads_f, gfilm_f = _field_backward(pf_f, rays, z_f, raw_f, g_raw, ctx.film, ctx.acts_f)
+        else:
+            g_c = _composite_bwd(raw_c, z_c, rays, g_rgb_c, g_depth_c, g_acc_c) if want_c else None
+            g_s = None
+            if want_f:
+                g_f = _composite_bwd(raw_f, z_f, rays, g_rgb_f, g_depth_f, g_acc_f)
+                if ctx.nf > 0:
+                    g_c, g_s = ops.split_grad(g_f, pos, ctx.nc, g_c)      # onto the coarse outputs' own gradient, if any
+                else:
+                    g_c = g_f if g_c is None else g_c.add_(g_f)
+                del g_f
+            if g_c is not None:
+                grads_c, gfilm_c = _field_backward(pf_c, rays, z_c, raw_c, g_c, ctx.film, ctx.acts_c)
+            if g_s is not None:
+                grads_f, gfilm_f = _field_backward(pf_f, rays, z_s, raw_s, g_s, ctx.film, ctx.acts_f)
         ctx.acts_c = ctx.acts_f = None          # release the saved activations
-        if same:
+        if pf_c is pf_f:
             if grads_c is not None and grads_f is not None:
                 torch._foreach_add_(grads_c, grads_f)
             merged = grads_c if grads_c is not None else grads_f

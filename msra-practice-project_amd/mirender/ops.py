@@ -106,6 +106,56 @@ def sample_fine(z_coarse: torch.Tensor, weights: torch.Tensor, near: float, far:
     return (z_fine, zs) if want_samples else z_fine
 
 
+def sample_fine_pos(z_coarse: torch.Tensor, weights: torch.Tensor, near: float, far: float, n_fine: int,
+                    exact_linspace: bool = True):
+    """sample_fine that also says where every input went: (z_fine [n,Nc+Nf], z_samples [n,Nf], pos [n,Nc+Nf] int32 with
+    pos[e] = index in z_fine of z_coarse[e] (e < Nc) or z_samples[e - Nc]).  For one field shared by both passes."""
+    lib = _lib.load()
+    dev = z_coarse.device
+    n, nc = z_coarse.shape
+    z_coarse, weights = _f32c(z_coarse, dev), _f32c(weights, dev)
+    z_fine = torch.empty((n, nc + n_fine), dtype=torch.float32, device=dev)
+    zs = torch.empty((n, n_fine), dtype=torch.float32, device=dev)
+    pos = torch.empty((n, nc + n_fine), dtype=torch.int32, device=dev)
+    zl = linspace_table(near, far, nc, dev) if exact_linspace else None
+    ul = linspace_table(0.0, 1.0, n_fine, dev) if exact_linspace else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_sample_fine_pos(n, float(near), float(far), nc, n_fine, _lib.ptr(zl), _lib.ptr(ul),
+                                          _lib.ptr(z_coarse), _lib.ptr(weights), _lib.ptr(zs), _lib.ptr(z_fine), _lib.ptr(pos),
+                                          _lib.stream_ptr(dev)), "mi_sample_fine_pos")
+    return z_fine, zs, pos
+
+
+def merge_raw(raw_c: torch.Tensor, raw_s: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    """raw_fine [n,Nc+Nf,4] in sorted order from the coarse pass's raw [n,Nc,4] and the field at z_samples [n,Nf,4]."""
+    lib = _lib.load()
+    dev = raw_c.device
+    n, nc = raw_c.shape[0], raw_c.shape[1]
+    nf = pos.shape[1] - nc
+    raw_f = torch.empty((n, nc + nf, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_merge_raw(n, nc, nf, _lib.ptr(raw_c), _lib.ptr(raw_s) if nf else None, _lib.ptr(pos),
+                                    _lib.ptr(raw_f), _lib.stream_ptr(dev)), "mi_merge_raw")
+    return raw_f
+
+
+def split_grad(g_raw_f: torch.Tensor, pos: torch.Tensor, nc: int, g_raw_c: torch.Tensor | None = None):
+    """The transpose of merge_raw: (g_raw_coarse [n,Nc,4] - added onto `g_raw_c` in place when given -, g_raw_samples
+    [n,Nf,4])."""
+    lib = _lib.load()
+    dev = g_raw_f.device
+    n, s = pos.shape
+    nf = s - nc
+    acc = g_raw_c is not None
+    if g_raw_c is None:
+        g_raw_c = torch.empty((n, nc, 4), dtype=torch.float32, device=dev)
+    g_s = torch.empty((n, nf, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.mi_split_grad(n, nc, nf, _lib.ptr(g_raw_f), _lib.ptr(pos), _lib.ptr(g_raw_c), int(acc),
+                                     _lib.ptr(g_s) if nf else None, _lib.stream_ptr(dev)), "mi_split_grad")
+    return g_raw_c, g_s
+
+
 def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int) -> torch.Tensor:
     """sample_pdf(bins[n,nb], weights[n,nb-1], N) -> [n,N] (render.py:27-56), any bins."""
     lib = _lib.load()
@@ -196,6 +246,10 @@ def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, 
             raise _lib.MiRenderError(f"t_rand must be [{n},{n_coarse}]")
     outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ((n, 3), (n,), (n,), (n, 3), (n,), (n,))]
     ws_bytes = lib.mi_render_workspace_bytes(n, n_coarse, n_fine)
+    if pf_c is pf_f and n_fine > 0:
+        # one field for both passes: with room for z_samples / their raw values / the merge positions the library evaluates
+        # the Nf new depths only (mi_render_rays, include/mi_render.h); without it the plain path, same results
+        ws_bytes += lib.mi_render_shared_field_extra_bytes(n, n_coarse, n_fine)
     guard = None
     if os.environ.get("MI_DEBUG_GUARDS") == "1":       # sentinel zone behind the workspace, checked after the call
         ws = torch.empty(int(ws_bytes) + 16384, dtype=torch.uint8, device=dev)
@@ -210,7 +264,7 @@ def render_rays_fused(pf_c: PackedField, pf_f: PackedField, rays: torch.Tensor, 
                                       _lib.ptr(film), _lib.ptr(rays), groups, rpg, float(near), float(far),
                                       n_coarse, n_fine, _lib.ptr(zl), _lib.ptr(ul), _lib.ptr(t_rand),
                                       int(seed) & (2 ** 64 - 1), int(ray0), *[_lib.ptr(o) for o in outs], _lib.ptr(ws),
-                                      _lib.stream_ptr(dev)), "mi_render_rays")
+                                      int(ws_bytes), _lib.stream_ptr(dev)), "mi_render_rays")
     if guard is not None and not bool((guard == 0xA5).all()):
         raise _lib.MiRenderError("mi_render_rays wrote past mi_render_workspace_bytes")
     return tuple(outs)
