@@ -19,7 +19,10 @@ Extra objects in the line:
   cpu_baseline  the CPU oracle (oracle/render_ref.py, PyTorch CPU, all host cores) on a bounded sample of
                 the same workload, rank 0, N=1 only; with it `psnr_vs_ref`: held-out-view PSNR of a TinyNeRF fitted
                 to a synthetic teacher scene by the HIP path and by the reference loop on the CPU (oracle/fit_ref.py)
-  train         N=1 only: the secondary training workloads (nerf 1024-ray step x40, pi_GAN C4 step x3)
+  train         N=1 only: the secondary training workloads (nerf 1024-ray step x40, pi_GAN C4 step x3).  pi_GAN passes ONE
+                field as coarse and fine model, so the renderer evaluates the fine pass's Nf new depths only:
+                `frac_of_fp32_mfma_peak` keeps SURVEY.md 8d's count of what the reference executes (120 evaluations per
+                ray), `frac_executed` counts what this renderer executes (108) - the one to hold against MFMA-busy
   collective    N>1 (or --force-collective): ranks seen by torch.distributed, per-rank mean MLP launch time,
                 all-gather time per frame
 """
