@@ -66,3 +66,57 @@ def test_sharded_frame_equals_single_process():
         assert np.array_equal(rgb.reshape(-1, 3), ref[0].numpy())     # shards are independent: exact
         assert np.array_equal(depth.reshape(-1), ref[1].numpy()) and np.array_equal(acc.reshape(-1), ref[2].numpy())
         assert all(np.allclose(g, 1.5) for g in grads)
+
+
+def _one_rank_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirender import dist as mdist
+    calls = {"gather": 0, "reduce": 0}
+    real_g, real_r = dist.all_gather_into_tensor, dist.all_reduce
+
+    def g(*a, **k):
+        calls["gather"] += 1
+        return real_g(*a, **k)
+
+    def r(*a, **k):
+        calls["reduce"] += 1
+        return real_r(*a, **k)
+    dist.all_gather_into_tensor, dist.all_reduce = g, r
+    res = {}
+    for force in (False, True):
+        mdist.FORCE_COLLECTIVE = force
+        rgb, depth, acc = mdist.render_image_sharded(_oracle_shard_renderer(), W, H)
+        p = [torch.nn.Parameter(torch.zeros(5, 3))]
+        p[0].grad = torch.full((5, 3), 2.5)
+        mdist.allreduce_grads(p)
+        res[force] = (rgb.numpy(), p[0].grad.numpy().copy(), dict(calls))
+    out[0] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_one_rank_group_skips_its_collectives_unless_forced():
+    """With one rank there is nothing to exchange: render_image_sharded / allreduce_grads skip the collectives - unless
+    mirender.dist.FORCE_COLLECTIVE is on (how the RCCL calls are executed on a one-GPU box, tests/test_gpu_rccl.py).
+    Either way the frame and the gradients are unchanged."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_one_rank_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    res = out[0]
+    assert res[False][2] == {"gather": 0, "reduce": 0}
+    assert res[True][2] == {"gather": 1, "reduce": 1}
+    assert np.array_equal(res[False][0], res[True][0]) and np.array_equal(res[False][1], res[True][1])
+    assert np.allclose(res[True][1], 2.5)
+
+
+def test_bench_finds_the_newest_rounds_profile(tmp_path, monkeypatch):
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for name in ("r01_pmc_c4.json", "r03_pmc_c4.json", "r02_pmc_c4.json", "r02_pmc_nerf_fwd.json"):
+        (prof / name).write_text("{}")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert os.path.basename(bench.newest_profile("pmc_c4.json")) == "r03_pmc_c4.json"
+    assert os.path.basename(bench.newest_profile("pmc_nerf_fwd.json")) == "r02_pmc_nerf_fwd.json"
+    assert bench.newest_profile("pmc_c5.json") is None
