@@ -263,7 +263,8 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step, **extra,
-                   "parallelism": f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU"},
+                   "parallelism": (f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU")
+                   + (" [REHEARSAL: all ranks on one device, gloo]" if os.environ.get("MI_BENCH_REHEARSAL") == "1" else "")},
         "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                        "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                        "grad_allreduce_bytes": int(sum(p.numel() for p in params) * 4),
