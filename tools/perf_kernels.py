@@ -46,3 +46,23 @@ def run(name, cls, n, s, near, far, groups=0):
 run("film", fields.FilmSirenNeRF, 4 * 16384, 36, 0.5, 1.5, groups=4)
 run("nerf", fields.NeRF, 8192, 192, 2.0, 6.0)
 run("siren", fields.SirenNeRF, 8192, 192, 2.0, 6.0)
+
+
+def pigan_inference():
+    """pi_GAN inference (Generator.forward under no_grad: 32 images 128x128, 12+24, one FiLM field for both passes): the
+    one-field path (the fine launch evaluates the 24 new depths only) against the two-field path on the same parameters
+    (a second PackedField view: every point evaluated, 48 per ray, as the reference does)."""
+    m = fields.FilmSirenNeRF().to(dev)
+    pf = fields.as_packed_field(m)
+    pf2 = fields.PackedField(pf.kind, pf.params)
+    n = 32 * 128 * 128
+    rays = torch.randn(n, 2, 3, device=dev); rays[:, 0] = torch.tensor([0., 0., 1.], device=dev); rays[:, 1, 2] = -1
+    film = torch.rand((32, 9, 512), device=dev) + 0.5
+    with torch.no_grad():
+        t1 = timed(lambda: ops.render_rays_fused(pf, pf, rays, 0.5, 1.5, 12, 24, film, None, 1))
+        t2 = timed(lambda: ops.render_rays_fused(pf, pf2, rays, 0.5, 1.5, 12, 24, film, None, 1))
+    print(f"pi_GAN inference, 32 x 128x128, 12+24: one-field path {t1 * 1e3:.1f} ms ({n / t1 / 1e6:.2f} M rays/s, 36 evaluations per ray) | "
+          f"every point evaluated {t2 * 1e3:.1f} ms ({n / t2 / 1e6:.2f} M rays/s, 48 per ray)", flush=True)
+
+
+pigan_inference()
