@@ -50,6 +50,10 @@ int mi_field_num_params(int kind);
 int64_t mi_field_packed_floats(int kind);
 /* Multiply-accumulates of the kind's linear layers per point (roofline accounting). */
 int64_t mi_field_macs(int kind);
+/* Shape of parameter tensor `index` (0 <= index < mi_field_num_params(kind)): weights [rows = out, cols = in], biases
+ * [rows = out, cols = 1].  What a host that does not hold an nn.Module needs in order to lay out the tensors it hands to
+ * mi_field_pack (the shapes of nerf/nerf.py:59-73, 128-146 and pi_GAN/modules.py:76-94). */
+int mi_field_param_shape(int kind, int index, int64_t* rows, int64_t* cols);
 /* Repack torch-layout parameters ([out,in] row-major weights, [out] biases; `params` is a
  * HOST array of n_params device pointers in state-dict order) into the packed stream the
  * fused MLP kernel consumes.  Replaces nothing in the reference: it is the hand-off from

@@ -39,6 +39,13 @@ const PackTable* host_table_bwd(int kind);
 static const int kNumLayers[MI_FIELD_KINDS] = {12, 12, 11, 11, 7};
 // multiply-accumulates of the linear layers per point (a6, a7, a8)
 static const int64_t kMacs[MI_FIELD_KINDS] = {591488, 559616, 526848, 526080, 248448};
+// (out, in) of every linear layer in mi_field_pack order (nerf/nerf.py:59-73, 128-146; pi_GAN/modules.py:76-94)
+static const int kLayerDims[MI_FIELD_KINDS][12][2] = {
+    {{256, 60}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 316}, {256, 256}, {256, 256}, {256, 256}, {128, 280}, {1, 256}, {3, 128}},
+    {{256, 3}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 259}, {256, 256}, {256, 256}, {256, 256}, {128, 259}, {1, 256}, {3, 128}},
+    {{256, 3}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {1, 256}, {256, 259}, {3, 256}, {0, 0}},
+    {{256, 3}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {256, 256}, {1, 256}, {256, 256}, {3, 256}, {0, 0}},
+    {{256, 60}, {256, 256}, {256, 256}, {256, 256}, {128, 280}, {1, 256}, {3, 128}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}}};
 
 static bool bad_kind(int kind) {
     if (kind < 0 || kind >= MI_FIELD_KINDS) { set_error("unknown field kind %d", kind); return true; }
@@ -78,6 +85,13 @@ const char* mi_last_error(void) { return g_err; }
 int mi_field_num_params(int kind) { return bad_kind(kind) ? MI_EINVAL : 2 * kNumLayers[kind]; }
 int64_t mi_field_packed_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : packed_floats(*host_table(kind)); }
 int64_t mi_field_macs(int kind) { return bad_kind(kind) ? MI_EINVAL : kMacs[kind]; }
+int mi_field_param_shape(int kind, int index, int64_t* rows, int64_t* cols) {
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (index < 0 || index >= 2 * kNumLayers[kind] || !rows || !cols) { set_error("mi_field_param_shape: bad arguments"); return MI_EINVAL; }
+    *rows = kLayerDims[kind][index / 2][0];
+    *cols = (index & 1) ? 1 : kLayerDims[kind][index / 2][1];
+    return MI_OK;
+}
 
 int mi_field_pack(int kind, const float* const* params, int n_params, float* packed, void* stream) {
     if (bad_kind(kind)) return MI_EINVAL;

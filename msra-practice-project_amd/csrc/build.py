@@ -94,8 +94,28 @@ def build(force=False, verbose=True, always=()):
     return OUT
 
 
+def build_host_example(verbose=True):
+    """tests/cabi/cabi_host: a C++ program that uses the library through include/mi_render.h alone (no Python, no torch) -
+    the link line a C / C++ host of the ABI uses.  Test infrastructure (tests/test_gpu_cabi_host.py runs it)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    root = os.path.dirname(PKG)
+    src = os.path.join(root, "tests", "cabi", "cabi_host.cpp")
+    out = os.path.join(root, "tests", "cabi", "cabi_host")
+    if _stale(out, [src, OUT, os.path.join(root, "include", "mi_render.h")]):
+        cmd = [hipcc, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(root, "include"), src, "-L", os.path.dirname(OUT), "-lmirender",
+               "-Wl,-rpath,$ORIGIN/../../msra-practice-project_amd/mirender", "-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd, timeout=600)
+        print(f"[build] {os.path.relpath(out, root)}: LINKED against libmirender.so", flush=True)
+    else:
+        print(f"[build] {os.path.relpath(out, root)}: REUSED", flush=True)
+    return out
+
+
 if __name__ == "__main__":
     if "--profile" in sys.argv:
         print(build_profile())
     else:
         print(build(force="--force" in sys.argv))
+        print(build_host_example())

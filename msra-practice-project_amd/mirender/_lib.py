@@ -30,6 +30,7 @@ SIGNATURES = {
     "mi_field_num_params": (_int, [_int]),
     "mi_field_packed_floats": (_i64, [_int]),
     "mi_field_macs": (_i64, [_int]),
+    "mi_field_param_shape": (_int, [_int, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
     "mi_field_pack": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),
     "mi_field_eval_points": (_int, [_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mi_field_eval_rays": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),

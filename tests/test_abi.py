@@ -46,6 +46,11 @@ def test_size_queries_need_no_gpu():
     for kind, spec in fields.SPECS.items():
         assert lib.mi_field_num_params(kind) == 2 * len(spec)
         assert lib.mi_field_macs(kind) == fields.MACS[kind]
+        rows, cols = ctypes.c_int64(), ctypes.c_int64()
+        for i, (_, (o, c)) in enumerate(spec):
+            assert lib.mi_field_param_shape(kind, 2 * i, rows, cols) == 0 and (rows.value, cols.value) == (o, c)
+            assert lib.mi_field_param_shape(kind, 2 * i + 1, rows, cols) == 0 and (rows.value, cols.value) == (o, 1)
+        assert lib.mi_field_param_shape(kind, 2 * len(spec), rows, cols) == -1
         # stream = 256-float pieces: every weight column block padded to 32, plus per-layer vector pieces
         n = lib.mi_field_packed_floats(kind)
         assert n % 256 == 0 and n >= fields.MACS[kind]
