@@ -44,6 +44,29 @@ def test_c3_full_frame_800x800_64_128():
     assert np.array_equal(out[0].reshape(-1, 3), rgb.cpu().numpy())
 
 
+def test_largest_single_launch_has_offsets_past_4_gib():
+    """Maximum sizes: render_image hands the library at most 2^20 rays per launch (render_core.MAX_RAYS_PER_LAUNCH).
+    At 64 + 128 samples such a launch holds 201 M fine points: raw_fine alone is 3.2 GB and the workspace 5.6 GB, so
+    byte offsets inside one buffer pass 2^31 and 2^32 (an 800x800 frame stays under 2^31 everywhere).  A 1200x1000
+    frame = one full 2^20-ray launch + a 151 424-ray remainder; its last rows (whose points sit at the far end of the
+    big buffers) and the rows either side of the launch boundary must be bit-equal to the same rays rendered in small
+    launches of their own."""
+    from mirender import fields, render_core
+    W, H = 1200, 1000
+    assert W * H > render_core.MAX_RAYS_PER_LAUNCH == 1 << 20
+    cm = fields.field_from_state_dict(synth.state_dict("nerf", seed=0, sharp="medium", bias_jitter=0.05), dev())
+    fm = fields.field_from_state_dict(synth.state_dict("nerf", seed=1, sharp="medium", bias_jitter=0.05), dev())
+    pose, focal = synth.pose_degrees(4.0, 30.0, -30.0), 1.3875 * W
+    with torch.no_grad():
+        whole = render_core._render_image_device(W, H, focal, pose, 2.0, 6.0, cm, fm, 64, 128, None, None, 5, 0, W * H)
+        for r0, n in (((1 << 20) - 2048, 2048), ((1 << 20) - 700, 1400), (1 << 20, 1024), (W * H - 1024, 1024), (0, 512)):
+            part = render_core._render_image_device(W, H, focal, pose, 2.0, 6.0, cm, fm, 64, 128, None, None, 5, r0, n)
+            for w, x in zip(whole, part):
+                assert torch.equal(w[r0:r0 + n], x), (r0, n)
+    assert bool(torch.isfinite(whole[0]).all()) and float(whole[0].std()) > 1e-2
+    torch.cuda.empty_cache()
+
+
 def _generator(res, nc, nf):
     from mirender import pigan
     torch.manual_seed(0)
