@@ -11,6 +11,8 @@ carry no gradient into the coarse pass.
 from __future__ import annotations
 
 import ctypes
+import os
+import sys
 
 import torch
 
@@ -133,6 +135,11 @@ def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothin
         parts.append(raw_k)
         budget -= need
         r_done = r1
+    if os.environ.get("MI_DEBUG_PLAN") == "1":            # what the memory planner decided for this pass
+        free, _t = torch.cuda.mem_get_info(pf.device)
+        sys.stderr.write(f"[mirender plan] {n} rays x {s}: kept {len(saved)} of {len(ranges)} ranges ({r_done} rays), "
+                         f"budget left {budget / 2**30:.1f} GiB, driver free {free / 2**30:.1f} GiB, torch reserved "
+                         f"{torch.cuda.memory_reserved(pf.device) / 2**30:.1f} allocated {torch.cuda.memory_allocated(pf.device) / 2**30:.1f} GiB\n")
     if r_done < n:
         if r_done % rpg:                                   # finish the image the kept ranges stopped inside
             r_next = (r_done // rpg + 1) * rpg
