@@ -214,6 +214,8 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
                    float far_, int n_coarse, int n_fine, const float* z_lin, const float* u_lin, const float* t_rand,
                    uint64_t seed, uint64_t ray0, float* rgb_c, float* depth_c, float* acc_c, float* rgb_f,
                    float* depth_f, float* acc_f, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n_groups < 0 || rays_per_group < 0 || n_coarse < 1 || n_fine < 0) { set_error("mi_render_rays: bad sizes"); return MI_EINVAL; }
+    if (n_groups * rays_per_group == 0) return MI_OK;          // no rays: nothing to launch, no buffer is touched
     if (!workspace || !rays || !rgb_c || !depth_c || !acc_c || !rgb_f || !depth_f || !acc_f) {
         set_error("mi_render_rays: null pointer argument");
         return MI_EINVAL;

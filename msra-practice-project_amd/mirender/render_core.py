@@ -102,6 +102,15 @@ def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fi
     if seed is None and t_rand is None:
         seed = _fresh_seed()
     pf_c, pf_f = fields.as_packed_field(coarse_model), fields.as_packed_field(fine_model)
+    if rays.shape[0] == 0:
+        # no rays (an empty batch, a rank of a group larger than the frame): six empty outputs; under autograd they hang
+        # off the parameters with zero gradients, so a loss over an empty shard still backpropagates
+        outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ((0, 3), (0,), (0,), (0, 3), (0,), (0,))]
+        leaves = [p for m in (coarse_model, fine_model) if isinstance(m, torch.nn.Module) for p in m.parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and leaves:
+            zero = sum(p.reshape(-1)[:1].sum() for p in leaves) * 0.0
+            outs = [o + zero for o in outs]
+        return tuple(outs)
     if pf_c is not None and pf_f is not None:
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in pf_c.params + pf_f.params)
         if fields.is_film(pf_c.kind) or fields.is_film(pf_f.kind):
@@ -145,6 +154,9 @@ def _render_image_device(width, height, focal, pose, near, far, coarse_model, fi
         tr = None if t_rand is None else t_rand[i - ray0:i - ray0 + m]   # row k of t_rand <-> ray ray0 + k
         out = render_rays(rays, near, far, coarse_model, fine_model, nc, nf, t_rand=tr, seed=seed, ray0=i)
         parts.append(out[3:6])
+    if not parts:                                          # an empty ray range (a rank of a group larger than the frame)
+        return (torch.empty((0, 3), dtype=torch.float32, device=dev), torch.empty(0, dtype=torch.float32, device=dev),
+                torch.empty(0, dtype=torch.float32, device=dev))
     if len(parts) == 1:
         return parts[0]
     return tuple(torch.cat([p[k] for p in parts]) for k in range(3))

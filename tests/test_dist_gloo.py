@@ -24,26 +24,28 @@ def _free_port():
     return p
 
 
-def _oracle_shard_renderer():
+def _oracle_shard_renderer(w=W, h=H):
     sd = synth.state_dict("tiny_nerf", seed=4, sharp=True)
     f = ofields.make_field("tiny_nerf", sd)
     pose = synth.pose_degrees(4.0, 20.0, -30.0)
-    rays = torch.from_numpy(R.rays_from_camera(W, H, 1.3875 * W, pose))
-    tr = synth.t_rand(W * H, NC, seed=2)
+    rays = torch.from_numpy(R.rays_from_camera(w, h, 1.3875 * w, pose))
+    tr = synth.t_rand(w * h, NC, seed=2)
 
     def shard(ray0, n):
+        if n == 0:                                   # more ranks than rays: this rank renders nothing
+            return torch.zeros(0, 3), torch.zeros(0), torch.zeros(0)
         with torch.no_grad():
             t = R.render_rays(rays[ray0:ray0 + n], 2.0, 6.0, f, f, NC, NF, tr[ray0:ray0 + n])
         return t.rgb_f, t.depth_f, t.acc_f
     return shard
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, w=W, h=H):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mirender import dist as mdist
-    torch.set_num_threads(2)
-    rgb, depth, acc = mdist.render_image_sharded(_oracle_shard_renderer(), W, H)
+    torch.set_num_threads(2 if world <= 2 else 1)
+    rgb, depth, acc = mdist.render_image_sharded(_oracle_shard_renderer(w, h), w, h)
     # gradient all-reduce: rank r holds grad = r+1 everywhere -> mean 1.5
     p = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
     for q in p:
@@ -66,6 +68,41 @@ def test_sharded_frame_equals_single_process():
         assert np.array_equal(rgb.reshape(-1, 3), ref[0].numpy())     # shards are independent: exact
         assert np.array_equal(depth.reshape(-1), ref[1].numpy()) and np.array_equal(acc.reshape(-1), ref[2].numpy())
         assert all(np.allclose(g, 1.5) for g in grads)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("w,h", [(13, 9), (3, 2)])
+def test_eight_ranks_ragged_and_empty_shards(w, h):
+    """world_size 8, the rank count of the driver's scaling run: 117 rays split 15/15/15/15/15/14/14/14 (ragged: the shards
+    are padded to the longest for the one all-gather and cut back afterwards), and 6 rays over 8 ranks (two ranks render
+    nothing and still take part in the collective).  Every rank ends with the single-process frame, bit for bit, and the
+    mean of eight ranks' gradients."""
+    from mirender import dist as mdist
+    world = 8
+    sizes = [b - a for a, b in (mdist.shard_range(w * h, r, world) for r in range(world))]
+    assert sum(sizes) == w * h and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out, w, h), nprocs=world, join=True)
+    # the CPU oracle's own result depends a little on how many rays go through MKL at once (a 1-ray sgemm rounds differently
+    # from a 15-ray one, and the sharp head's resampling amplifies it): the reference frame is assembled from the same
+    # shard sizes in ONE process, which is exactly what the collective has to reproduce; the whole-frame render agrees to 1e-2
+    one = _oracle_shard_renderer(w, h)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)                        # like the eight workers (MKL's result also depends on its thread count)
+    try:
+        shards = [one(*(lambda a, b: (a, b - a))(*mdist.shard_range(w * h, r, world))) for r in range(world)]
+        whole = one(0, w * h)
+    finally:
+        torch.set_num_threads(threads)
+    ref = [torch.cat([s[k] for s in shards]).numpy() for k in range(3)]
+    assert np.abs(ref[0] - whole[0].numpy()).max() < 1e-2
+    for rank in range(world):
+        rgb, depth, acc, grads = out[rank]
+        assert rgb.shape == (h, w, 3) and depth.shape == (h, w, 1) and acc.shape == (h, w, 1)
+        assert np.array_equal(rgb.reshape(-1, 3), ref[0])
+        assert np.array_equal(depth.reshape(-1), ref[1]) and np.array_equal(acc.reshape(-1), ref[2])
+        assert all(np.allclose(g, 4.5) for g in grads)                 # mean of 1..8
 
 
 def _one_rank_worker(rank, world, port, out):

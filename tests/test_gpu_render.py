@@ -485,3 +485,28 @@ def test_render_video_overlaps_copies_without_mixing_frames(nerf_render):
     empty = nerf_render.render_video(W, H, 1.3875 * W, [], 2.0, 6.0, cm, fm, nc, nf)
     assert [v.shape for v in empty] == [(0, H, W, 3), (0, H, W, 1), (0, H, W, 1)]
 
+
+
+def test_no_rays_is_a_valid_input(nerf_render):
+    """Empty inputs: render_rays on zero rays (an empty batch; a rank of a group with more ranks than rays,
+    tests/test_dist_gloo.py) returns six empty tensors, under autograd with zero gradients for the parameters; an empty
+    ray range of a frame likewise; the C ABI takes n = 0 without touching any buffer."""
+    from mirender import _lib, render_core
+    cm = model("nerf", synth.state_dict("nerf", seed=5, sharp="medium"))
+    fm = model("nerf", synth.state_dict("nerf", seed=6, sharp="medium"))
+    rays = torch.empty(0, 2, 3, device=dev())
+    with torch.no_grad():
+        out = render_core.render_rays(rays, 2.0, 6.0, cm, fm, 8, 8)
+    assert [tuple(o.shape) for o in out] == [(0, 3), (0,), (0,)] * 2 and not any(o.requires_grad for o in out)
+    out = render_core.render_rays(rays, 2.0, 6.0, cm, fm, 8, 8)
+    (out[3].sum() + out[0].sum()).backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in list(cm.parameters()) + list(fm.parameters()))
+    part = render_core._render_image_device(16, 16, 22.2, synth.pose_degrees(4.0, 0.0, -30.0), 2.0, 6.0, cm, fm, 8, 8, None, None, 3, 40, 0)
+    assert [tuple(o.shape) for o in part] == [(0, 3), (0,), (0,)]
+    lib = _lib.load()
+    assert lib.mi_render_rays(0, None, 0, None, None, None, 1, 0, 2.0, 6.0, 8, 8, None, None, None, 0, 0,
+                              None, None, None, None, None, None, None, 0, None) == 0
+    assert lib.mi_render_rays(0, None, 0, None, None, None, 1, 4, 2.0, 6.0, 8, 8, None, None, None, 0, 0,
+                              None, None, None, None, None, None, None, 0, None) == -1            # rays but no buffers
+    assert lib.mi_render_rays(0, None, 0, None, None, None, -1, 4, 2.0, 6.0, 8, 8, None, None, None, 0, 0,
+                              None, None, None, None, None, None, None, 0, None) == -1 and b"bad sizes" in lib.mi_last_error()
