@@ -725,14 +725,25 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
     for (int st = 0; st < n_stages; ++st) {
         const int b = st & 1;
         __syncthreads();                                             // stage st has landed (vmcnt(0) + barrier)
-        const float* As = smem + b * STAGE + 128 * wm + 4 * i;
-        const float* Bs = smem + b * STAGE + T * TM + 32 * CB * wk + CB * i;
+        // this wave's first point pair of the stage; step sidx reads rows 2 KS sidx further on (an immediate offset)
+        const float* As = smem + b * STAGE + 128 * wm + 4 * i + (2 * ks + h) * TM;
+        const float* Bs = smem + b * STAGE + T * TM + 32 * CB * wk + CB * i + (2 * ks + h) * TK;
         const bool more = st + 1 < n_stages;
+        // Operands one step ahead: the reads of step s + 1 are issued at the top of step s and pinned there, so their LDS
+        // latency runs under the 4 CB MFMAs of step s.  (Left to the scheduler, the A operand of a step was read three MFMAs
+        // before the step began with an s_waitcnt lgkmcnt(0) right behind it - the matrix pipe drained at every step: the
+        // ISA of round 2's kernel, tools/isa_stats.py.)  Only the first step of a stage waits for LDS.
+        f32x4 av = *reinterpret_cast<const f32x4*>(As);
+        bvec bv = *reinterpret_cast<const bvec*>(Bs);
         static_for<STEPS>([&](auto sc) {
             constexpr int sidx = decltype(sc)::value;
-            const int j = 2 * (ks + KS * sidx) + h;
-            const f32x4 av = *reinterpret_cast<const f32x4*>(As + j * TM);
-            const bvec bv = *reinterpret_cast<const bvec*>(Bs + j * TK);
+            f32x4 av_n = av;
+            bvec bv_n = bv;
+            if constexpr (sidx + 1 < STEPS) {
+                av_n = *reinterpret_cast<const f32x4*>(As + 2 * KS * (sidx + 1) * TM);
+                bv_n = *reinterpret_cast<const bvec*>(Bs + 2 * KS * (sidx + 1) * TK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             bsum += av;
             static_for<4>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
@@ -747,6 +758,8 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
+            av = av_n;
+            bv = bv_n;
         });
     }
     // The k-split waves of a workgroup (KS = 2 or 4 for the narrow tiles) hold partial sums of the SAME tile: they are

@@ -491,16 +491,27 @@ template <int MB>
 __device__ __forceinline__ float head_dot(const f32x16 (&X)[8], const float* aux, int piece, int h) {
     const lds4_t p = lds_base(aux + h * 16);
     float s0 = 0.f, s1 = 0.f;
+    // The weights of block m + 1 are read while block m's 16 FMAs run (left to itself the compiler keeps ONE read in
+    // flight and waits for it after four FMAs: 32 half-hidden LDS latencies per head, tools/isa_lds_waits.py).
+    f32x4 w[4], wn[4];
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int rg = 0; rg < 4; ++rg) w[rg] = p[piece * 64 + rg];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        if (m + 1 < MB) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) wn[rg] = p[piece * 64 + (m + 1) * 8 + rg];
+        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 w = p[piece * 64 + m * 8 + rg];
-            s0 = fmaf(w.x, X[m][4 * rg + 0], s0);
-            s1 = fmaf(w.y, X[m][4 * rg + 1], s1);
-            s0 = fmaf(w.z, X[m][4 * rg + 2], s0);
-            s1 = fmaf(w.w, X[m][4 * rg + 3], s1);
+            s0 = fmaf(w[rg].x, X[m][4 * rg + 0], s0);
+            s1 = fmaf(w[rg].y, X[m][4 * rg + 1], s1);
+            s0 = fmaf(w[rg].z, X[m][4 * rg + 2], s0);
+            s1 = fmaf(w[rg].w, X[m][4 * rg + 3], s1);
         }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) w[rg] = wn[rg];
+    }
     float s = s0 + s1;
     s += __shfl_xor(s, 32);
     return s;
