@@ -289,7 +289,7 @@ def psnr_vs_ref(dev):
     """The metric's "PSNR vs ref" clause on trained results: student pairs fitted to the synthetic teacher scene of
     oracle/fit_ref.py (24x24 views, 16+16 samples, the loop of nerf/train_nerf.py:124-176) by the HIP path and by the same
     loop on the CPU - same initial weights, rays and jitter; held-out-view PSNR of both.  TinyNeRF (PE + ReLU): 60 Adam
-    steps of 256 rays at 5e-4, CPU side = the oracle's loop run here; SirenNeRF (the sin family): 15 Adam steps over all
+    steps of 256 rays at 5e-4, CPU side = the oracle's loop run here; SirenNeRF and FilmSirenNeRF (fixed FiLM row): 15 Adam steps over all
     3 456 rays at 1e-5, CPU side = the REFERENCE's own code run in the build container (tests/golden/fit_r03_siren_adam.npz:
     a live CPU fit of an 8x256 sin pair costs ~2 minutes on this host).  Both regimes are reproducible under a 1e-6
     perturbation of the initial weights to < 1e-3 dB (tests/test_gpu_psnr.py gates them hard).  Part of the CPU-baseline
@@ -297,7 +297,8 @@ def psnr_vs_ref(dev):
     from mirender import fields, render_core
     from oracle import fit_ref, render_ref as R
     out = {}
-    for student, lr0, batch, steps, fixture in (("tiny_nerf", 5e-4, 256, 60, None), ("siren_nerf", 1e-5, 0, 15, "fit_r03_siren_adam")):
+    for student, lr0, batch, steps, fixture in (("tiny_nerf", 5e-4, 256, 60, None), ("siren_nerf", 1e-5, 0, 15, "fit_r03_siren_adam"),
+                                                 ("film_siren_nerf", 1e-5, 0, 15, "fit_r03_film_adam")):
         images = None
         if fixture is not None:             # the reference run fitted the teacher views as the build container rendered them
             with np.load(os.path.join(ROOT, "tests", "golden", "fit_r03_scene.npz")) as f:
@@ -312,12 +313,13 @@ def psnr_vs_ref(dev):
                 assert int(f["steps"]) == steps and abs(float(f["lr0"]) - lr0) < 1e-12
             cpu_side = f"the reference's own code, build container (tests/golden/{fixture}.npz)"
         cm, fm = fields.field_from_state_dict(scene.student_init[0], dev), fields.field_from_state_dict(scene.student_init[1], dev)
+        film = None if scene.film is None else scene.film.to(dev).reshape(1, 9, 512)    # FiLM: a fixed row, the field alone trains
         opt = fit_ref.make_optimizer(list(cm.parameters()) + list(fm.parameters()), "adam", lr0)
         loss, worst = None, 0.0
         for step in range(steps):
             rays, rgb, tr = scene.batch(step, batch)
             rgb = rgb.to(dev)
-            o = render_core.render_rays(rays.to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf, t_rand=tr.to(dev))
+            o = render_core.render_rays(rays.to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf, t_rand=tr.to(dev), film=film)
             loss = torch.mean((o[3] - rgb) ** 2) + torch.mean((o[0] - rgb) ** 2)
             opt.zero_grad()
             loss.backward()
@@ -327,7 +329,7 @@ def psnr_vs_ref(dev):
             worst = max(worst, abs(float(loss) - cpu_losses[step]) / cpu_losses[step])
         with torch.no_grad():
             held = render_core.render_rays(scene.rays[-1].to(dev), fit_ref.NEAR, fit_ref.FAR, cm, fm, scene.nc, scene.nf,
-                                           t_rand=scene.heldout_jitter().to(dev))
+                                           t_rand=scene.heldout_jitter().to(dev), film=film)
         hip_psnr = R.psnr(held[3].cpu().numpy(), scene.images[-1].numpy())
         out[student] = {"hip_db": hip_psnr, "cpu_reference_loop_db": cpu_psnr, "diff_db": hip_psnr - cpu_psnr,
                         "final_loss_hip": float(loss), "final_loss_cpu": cpu_losses[-1], "max_rel_loss_diff": worst,
