@@ -50,6 +50,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+METRIC = "rays/sec (+ ms/800\u00b2 frame @64 samples) at 1/2/4/8 MI355X; PSNR vs ref"      # BASELINE.json's metric, verbatim
+
 W = H = 800
 NEAR, FAR = 2.0, 6.0            # nerf/configs/lego.json:10-11
 NC, NF = 64, 128
@@ -525,7 +527,7 @@ def main():
     if rank == 0:
         rays_per_s = W * H * args.steps / elapsed
         line = {
-            "metric": "rays/sec (+ ms/800^2 frame @64 samples) at 1/2/4/8 MI355X; PSNR vs ref",
+            "metric": METRIC,
             "value": rays_per_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -136,6 +136,15 @@ def test_reference_class_layouts_are_recognised():
     assert fields.detect_kind(inner) == fields.FILM_SIREN_NERF
 
 
+def test_bench_metric_is_baseline_jsons_metric():
+    """bench.py's headline line carries BASELINE.json's metric string verbatim (the driver matches on it)."""
+    import json
+    import os
+    import bench
+    with open(os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "BASELINE.json")) as f:
+        assert bench.METRIC == json.load(f)["metric"]
+
+
 def test_bench_spawns_its_own_ranks(monkeypatch):
     """`python bench.py --gpus N` from a plain shell (no torch.distributed.run environment) must start N fresh rank
     processes itself - before any GPU call, never by re-exec'ing - and relay their exit code."""
