@@ -540,7 +540,9 @@ def main():
             "roofline": roofline,
         }
         if f64_s is not None:
-            line["frame64"] = {"ms_per_frame": f64_s * 1e3, "rays_per_s": W * H / f64_s,
+            f64_tflops = W * H * NC * flops_pt / f64_s / 1e12          # the whole frame's wall time, not only its MLP launch
+            line["frame64"] = {"ms_per_frame": f64_s * 1e3, "rays_per_s": W * H / f64_s, "tflops": f64_tflops,
+                               "frac_of_fp32_mfma_peak": f64_tflops / PEAK_FP32_MFMA_TFLOPS,
                                "workload": "800x800 frame, 64 samples/ray, one NeRF 8x256 (Nf=0)"}
         if collective is not None:
             line["collective"] = collective
