@@ -158,11 +158,13 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
 
 /* ---- training: what autograd does for the reference (train_nerf.py:151-168) ------------------ */
 
-/* Backward of raw_to_outputs (nerf/render.py:91-101): dL/d(rgb, depth, acc) -> dL/d(raw) [n,S,4].
- * Any of g_rgb [n,3], g_depth [n], g_acc [n] may be NULL (= zero).  z and rays carry no gradient
- * (z_samples is detached at render.py:141). */
+/* Backward of raw_to_outputs (nerf/render.py:91-103): dL/d(rgb, depth, acc, weights) -> dL/d(raw) [n,S,4].
+ * Any of g_rgb [n,3], g_depth [n], g_acc [n], g_weights [n,S] may be NULL (= zero); g_weights is the cotangent of the
+ * weights the function also returns (render.py:103; render_rays itself detaches what it derives from them, :141).
+ * z and rays carry no gradient (z_samples is detached at render.py:141). */
 int mi_composite_bwd(int64_t n, int n_samples, const float* raw, const float* z, const float* rays,
-                     const float* g_rgb, const float* g_depth, const float* g_acc, float* g_raw, void* stream);
+                     const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights, float* g_raw,
+                     void* stream);
 
 /* Transposed weight stream for the backward chain (second packed buffer, refreshed with the weights). */
 int64_t mi_field_packed_bwd_floats(int kind);
@@ -180,6 +182,11 @@ int64_t mi_field_bwd_partial_floats(int64_t points);
 int mi_field_eval_rays_train(int kind, const float* packed, const float* film, const float* rays, const float* z,
                              int64_t n_groups, int64_t rays_per_group, int n_samples, float* raw, float* acts,
                              void* stream);
+
+/* mi_field_eval_points that also saves every linear layer's input (the training forward of `network(x)` called on
+ * its own, nerf/render.py:73 outside render_rays): acts [mi_field_train_acts_floats(kind) * n_groups*points_per_group]. */
+int mi_field_eval_points_train(int kind, const float* packed, const float* film, const float* x, int64_t n_groups,
+                               int64_t points_per_group, float* out, float* acts, void* stream);
 
 /* Backward of network(inputs) over n_groups*points_per_group points: g_raw [points,4] = dL/d(raw) ->
  * parameter gradients (and, for FiLM kinds, the gradient of the FiLM table).

@@ -79,7 +79,7 @@ using namespace mi;
 
 extern "C" {
 
-int mi_abi_version(void) { return 3; }
+int mi_abi_version(void) { return 4; }
 const char* mi_last_error(void) { return g_err; }
 
 int mi_field_num_params(int kind) { return bad_kind(kind) ? MI_EINVAL : 2 * kNumLayers[kind]; }
@@ -280,9 +280,10 @@ int mi_render_rays(int kind_coarse, const float* packed_coarse, int kind_fine, c
 }
 
 int mi_composite_bwd(int64_t n, int n_samples, const float* raw, const float* z, const float* rays,
-                     const float* g_rgb, const float* g_depth, const float* g_acc, float* g_raw, void* stream) {
+                     const float* g_rgb, const float* g_depth, const float* g_acc, const float* g_weights, float* g_raw,
+                     void* stream) {
     if (n < 0 || n_samples < 1 || !raw || !z || !rays || !g_raw) { set_error("mi_composite_bwd: bad arguments"); return MI_EINVAL; }
-    return launch_composite_bwd(n, n_samples, raw, z, rays, g_rgb, g_depth, g_acc, g_raw, (hipStream_t)stream);
+    return launch_composite_bwd(n, n_samples, raw, z, rays, g_rgb, g_depth, g_acc, g_weights, g_raw, (hipStream_t)stream);
 }
 
 int64_t mi_field_packed_bwd_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : packed_floats(*host_table_bwd(kind)); }
@@ -305,6 +306,14 @@ int mi_field_eval_rays_train(int kind, const float* packed, const float* film, c
     if (train_acts_floats(kind) < 0) { set_error("kind %d has no training path yet", kind); return MI_EINVAL; }
     return eval_common(kind, packed, film, rays, z, n_groups, rays_per_group * n_samples, rays_per_group, n_samples, 1,
                        raw, (hipStream_t)stream, acts);
+}
+
+int mi_field_eval_points_train(int kind, const float* packed, const float* film, const float* x, int64_t n_groups,
+                               int64_t points_per_group, float* out, float* acts, void* stream) {
+    if (!acts) { set_error("mi_field_eval_points_train: bad arguments"); return MI_EINVAL; }
+    if (bad_kind(kind)) return MI_EINVAL;
+    if (train_acts_floats(kind) < 0) { set_error("kind %d has no training path yet", kind); return MI_EINVAL; }
+    return eval_common(kind, packed, film, x, nullptr, n_groups, points_per_group, 0, 1, 0, out, (hipStream_t)stream, acts);
 }
 
 int64_t mi_field_film_partial_floats(int64_t n_groups, int64_t points_per_group) {

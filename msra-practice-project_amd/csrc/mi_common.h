@@ -89,7 +89,7 @@ int launch_sample_coarse(int64_t n, float near_, float far_, int nc, const float
 int launch_composite(int64_t n, int S, const float* raw, const float* z, const float* rays, float* rgb, float* depth,
                      float* acc, float* weights, hipStream_t stream);
 int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,
-                         const float* g_depth, const float* g_acc, float* g_raw, hipStream_t stream);
+                         const float* g_depth, const float* g_acc, const float* g_w, float* g_raw, hipStream_t stream);
 int64_t image_metrics_workspace_floats(int images, int channels, int H, int W);
 int launch_image_metrics(const float* img1, const float* img2, int images, int channels, int H, int W,
                          const float* window, int window_size, float* workspace, float* out, hipStream_t stream);

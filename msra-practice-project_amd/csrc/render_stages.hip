@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n, int S, co
                                                             const float* __restrict__ g_rgb,
                                                             const float* __restrict__ g_depth,
                                                             const float* __restrict__ g_acc,
+                                                            const float* __restrict__ g_w,
                                                             float* __restrict__ g_raw) {
     const int lane = threadIdx.x & 63;
     const int sub = lane & (G - 1);
@@ -208,7 +209,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(int64_t n, int S, co
         const float e = expf(-c.w * delta);
         const float alpha = 1.0f - e;
         const float Tk = in && live ? out[kc].w : 0.f;
-        const float Gk = gr * (c.x - 1.f) + gg * (c.y - 1.f) + gb * (c.z - 1.f) + gd * zk + ga;
+        // dL/dw_k; g_w = the cotangent of the returned weights themselves (raw_to_outputs hands them out, render.py:103)
+        float Gk = gr * (c.x - 1.f) + gg * (c.y - 1.f) + gb * (c.z - 1.f) + gd * zk + ga;
+        if (g_w) Gk += g_w[rc * S + kc];
         // affine map of this sample, R_k = A + M * R_{k+1}; composed towards higher lanes
         float M = in ? (1.0f - alpha) + 1e-10f : 1.f, A = in ? Gk * alpha : 0.f;
 #pragma unroll
@@ -489,13 +492,13 @@ int launch_composite(int64_t n, int S, const float* raw, const float* z, const f
 }
 
 int launch_composite_bwd(int64_t n, int S, const float* raw, const float* z, const float* rays, const float* g_rgb,
-                         const float* g_depth, const float* g_acc, float* g_raw, hipStream_t stream) {
+                         const float* g_depth, const float* g_acc, const float* g_w, float* g_raw, hipStream_t stream) {
     if (n <= 0) return 0;
     const int G = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
     const dim3 grid((unsigned)((n * G + 255) / 256)), block(256);
-    if (G == 16) hipLaunchKernelGGL((composite_bwd_kernel<16>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_raw);
-    else if (G == 32) hipLaunchKernelGGL((composite_bwd_kernel<32>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_raw);
-    else hipLaunchKernelGGL((composite_bwd_kernel<64>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_raw);
+    if (G == 16) hipLaunchKernelGGL((composite_bwd_kernel<16>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_w, g_raw);
+    else if (G == 32) hipLaunchKernelGGL((composite_bwd_kernel<32>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_w, g_raw);
+    else hipLaunchKernelGGL((composite_bwd_kernel<64>), grid, block, 0, stream, n, S, raw, z, rays, g_rgb, g_depth, g_acc, g_w, g_raw);
     return check_launch("composite_bwd");
 }
 

@@ -55,13 +55,14 @@ SIGNATURES = {
     "mi_render_shared_field_extra_bytes": (_i64, [_i64, _int, _int]),
     "mi_render_rays": (_int, [_int, _vp, _int, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _int, _int, _vp, _vp, _vp,
                               _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "mi_composite_bwd": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_composite_bwd": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_field_packed_bwd_floats": (_i64, [_int]),
     "mi_field_pack_bwd": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),
     "mi_field_train_acts_floats": (_i64, [_int]),
     "mi_field_train_grads_floats": (_i64, [_int]),
     "mi_field_bwd_partial_floats": (_i64, [_i64]),
     "mi_field_eval_rays_train": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp, _vp]),
+    "mi_field_eval_points_train": (_int, [_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "mi_field_film_partial_floats": (_i64, [_i64, _i64]),
     "mi_field_backward": (_int, [_int, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, ctypes.POINTER(_vp),
                                  ctypes.POINTER(_vp), _int, _vp, _vp]),
@@ -71,6 +72,8 @@ SIGNATURES = {
     "mi_event_elapsed_ms": (_int, [_vp, _vp, ctypes.POINTER(_f32)]),
     "mi_render_set_mlp_events": (None, [_vp, _vp, _vp, _vp]),
 }
+
+ABI_VERSION = 4      # include/mi_render.h as of this binding (mi_abi_version() of the library must equal it)
 
 _lib = None
 
@@ -89,6 +92,16 @@ def load():
             f"{LIB_PATH} not found: build it with `python msra-practice-project_amd/csrc/build.py` "
             "(the HIP library is required; there is no fallback path)")
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    # the signatures below are those of ONE ABI version: a stale or foreign library (MI_DIAG_LIB in tests/conftest.py makes
+    # loading another one a supported path) must be refused before any call passes it arguments in the wrong order
+    try:
+        lib.mi_abi_version.restype = ctypes.c_int
+        have = lib.mi_abi_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise MiRenderError(f"{LIB_PATH} has ABI version {have}, this binding is written against {ABI_VERSION}: rebuild it "
+                            "with `python msra-practice-project_amd/csrc/build.py --force`")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res

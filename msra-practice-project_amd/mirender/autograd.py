@@ -63,19 +63,41 @@ def _groups(pf, film, n_rays):
     return f, f.shape[0], n_rays // f.shape[0]
 
 
+def _shape(rays, z):
+    """(units, samples per unit) of a pass.  Two input forms share every function below: points o + d z on rays
+    (`rays` [n,2,3], `z` [n,S]: run_network inside render_rays, render.py:134-135) and free-standing points (`rays` holds
+    x [M,6] = position | view direction, `z` is None: `network(x)` called on its own, render.py:73) - then a unit is a point."""
+    return (rays.shape[0], 1) if z is None else tuple(z.shape)
+
+
+def _cut(z, r0, r1):
+    return None if z is None else z[r0:r1]
+
+
+def _forward_plain(pf: fields.PackedField, rays, z, film):
+    if z is None:
+        return fields.eval_points(pf, rays, film).reshape(-1, 1, 4)
+    return ops.field_eval_rays(pf, rays, z, film)
+
+
 def _forward_saving(pf: fields.PackedField, rays, z, film):
     """Field forward that also keeps every layer's input (training forward).  Returns (raw, acts)."""
     lib = _lib.load()
     dev = pf.device
-    n, s = z.shape
+    n, s = _shape(rays, z)
     pts = n * s
     f, groups, rpg = _groups(pf, film, n)
     acts, acts_g = _guarded(lib.mi_field_train_acts_floats(pf.kind) * pts, dev)
     raw = torch.empty((n, s, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.mi_field_eval_rays_train(pf.kind, _lib.ptr(pf.refresh()), _lib.ptr(f), _lib.ptr(rays), _lib.ptr(z),
-                                                groups, rpg, s, _lib.ptr(raw), _lib.ptr(acts), _lib.stream_ptr(dev)),
-                   "mi_field_eval_rays_train")
+        if z is None:
+            _lib.check(lib.mi_field_eval_points_train(pf.kind, _lib.ptr(pf.refresh()), _lib.ptr(f), _lib.ptr(rays), groups, rpg,
+                                                      _lib.ptr(raw), _lib.ptr(acts), _lib.stream_ptr(dev)),
+                       "mi_field_eval_points_train")
+        else:
+            _lib.check(lib.mi_field_eval_rays_train(pf.kind, _lib.ptr(pf.refresh()), _lib.ptr(f), _lib.ptr(rays), _lib.ptr(z),
+                                                    groups, rpg, s, _lib.ptr(raw), _lib.ptr(acts), _lib.stream_ptr(dev)),
+                       "mi_field_eval_rays_train")
     _check_guard(acts_g, "saved layer inputs (mi_field_train_acts_floats)")
     return raw, acts
 
@@ -119,7 +141,7 @@ def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothin
     holds (with all_or_nothing: for every range or for none); the rest is evaluated by the plain kernel and
     recomputed range by range in backward."""
     lib = _lib.load()
-    n, s = z.shape
+    n, s = _shape(rays, z)
     per_point = 4 * lib.mi_field_train_acts_floats(pf.kind)
     f_all, rpg, ranges = _chunk_ranges(pf, n, s, film)
     per_point_bwd = per_point + 4 * lib.mi_field_train_grads_floats(pf.kind)
@@ -131,7 +153,7 @@ def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothin
         need = per_point * (r1 - r0) * s
         if need > budget:
             break
-        raw_k, saved[k] = _forward_saving(pf, rays[r0:r1], z[r0:r1], _film_of_range(f_all, rpg, r0, r1))
+        raw_k, saved[k] = _forward_saving(pf, rays[r0:r1], _cut(z, r0, r1), _film_of_range(f_all, rpg, r0, r1))
         parts.append(raw_k)
         budget -= need
         r_done = r1
@@ -143,10 +165,10 @@ def _forward_pass(pf: fields.PackedField, rays, z, film, cap: int, all_or_nothin
     if r_done < n:
         if r_done % rpg:                                   # finish the image the kept ranges stopped inside
             r_next = (r_done // rpg + 1) * rpg
-            parts.append(ops.field_eval_rays(pf, rays[r_done:r_next], z[r_done:r_next], _film_of_range(f_all, rpg, r_done, r_next)))
+            parts.append(_forward_plain(pf, rays[r_done:r_next], _cut(z, r_done, r_next), _film_of_range(f_all, rpg, r_done, r_next)))
             r_done = r_next
         if r_done < n:
-            parts.append(ops.field_eval_rays(pf, rays[r_done:], z[r_done:], None if f_all is None else f_all[r_done // rpg:]))
+            parts.append(_forward_plain(pf, rays[r_done:], _cut(z, r_done, n), None if f_all is None else f_all[r_done // rpg:]))
     return (parts[0] if len(parts) == 1 else torch.cat(parts)), saved
 
 
@@ -157,7 +179,7 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
     lib = _lib.load()
     dev = pf.device
     grads_f = lib.mi_field_train_grads_floats(pf.kind)
-    n, s = z.shape
+    n, s = _shape(rays, z)
     f_all, rpg, ranges = _chunk_ranges(pf, n, s, film)
     saved = {} if saved is None else saved
     total = None
@@ -185,7 +207,7 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
         if k in saved:
             acts_c, raw_c = saved.pop(k), raw[r0:r1]
         else:
-            raw_c, acts_c = _forward_saving(pf, rays[r0:r1], z[r0:r1], f_c)
+            raw_c, acts_c = _forward_saving(pf, rays[r0:r1], _cut(z, r0, r1), f_c)
         arr = (ctypes.c_void_p * len(out))(*[t.data_ptr() for t in out])
         # FiLM kinds: d gamma = <W, dW_image> + b . db_image needs the parameters themselves
         par = (ctypes.c_void_p * len(out))(*[p.data_ptr() for p in pf.params]) if f_all is not None else None
@@ -201,6 +223,7 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
         return out
 
     for k, (r0, r1) in enumerate(ranges):
+        retry = False
         try:
             out = one_range(k, r0, r1)
         except torch.cuda.OutOfMemoryError:
@@ -210,6 +233,11 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
             # same gradients bit for bit (tests/test_gpu_train.py), bounded memory.
             if not saved:
                 raise
+            retry = True
+        if retry:
+            # outside the handler: while it runs, the exception's traceback keeps the failed call's frame - and with it
+            # whatever that call had already allocated (gradient rows, scratch) - alive, and empty_cache() could not
+            # hand those blocks back exactly when the retry needs them
             saved.clear()
             torch.cuda.empty_cache()
             out = one_range(k, r0, r1)
@@ -220,17 +248,17 @@ def _field_backward(pf: fields.PackedField, rays, z, raw, g_raw, film, saved=Non
     return total, g_film
 
 
-def _composite_bwd(raw, z, rays, g_rgb, g_depth, g_acc):
+def _composite_bwd(raw, z, rays, g_rgb, g_depth, g_acc, g_w=None):
     lib = _lib.load()
     dev = raw.device
     n, s = z.shape
     g_raw = torch.empty_like(raw)
     c = lambda t: None if t is None else t.detach().to(device=dev, dtype=torch.float32).contiguous()  # noqa: E731
-    g_rgb, g_depth, g_acc = c(g_rgb), c(g_depth), c(g_acc)
+    g_rgb, g_depth, g_acc, g_w = c(g_rgb), c(g_depth), c(g_acc), c(g_w)
     with torch.cuda.device(dev):
         _lib.check(lib.mi_composite_bwd(n, s, _lib.ptr(raw), _lib.ptr(z), _lib.ptr(rays), _lib.ptr(g_rgb),
-                                        _lib.ptr(g_depth), _lib.ptr(g_acc), _lib.ptr(g_raw), _lib.stream_ptr(dev)),
-                   "mi_composite_bwd")
+                                        _lib.ptr(g_depth), _lib.ptr(g_acc), _lib.ptr(g_w), _lib.ptr(g_raw),
+                                        _lib.stream_ptr(dev)), "mi_composite_bwd")
     return g_raw
 
 
@@ -335,3 +363,104 @@ def render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed, r
     params = list(pf_c.params) if pf_c is pf_f else list(pf_c.params) + list(pf_f.params)
     return _RenderRaysFn.apply(pf_c, pf_f, rays.detach(), float(near), float(far), int(nc), int(nf), film,
                                None if t_rand is None else t_rand.detach(), int(seed), int(ray0), *params)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# The stages on their own, differentiable: what the reference's plain torch ops give every caller of raw_to_outputs /
+# run_network / network(x) (nerf/render.py:59-103), and what render_rays needs when a model is NOT one of the fused
+# kinds (any callable, a w_0 != 30 look-alike, a mixed pair): the callable's own autograd graph reaches `raw`, and
+# compositing / the fused side of a mixed pair continue it on the HIP kernels.
+# ----------------------------------------------------------------------------------------------------------------
+def _no_grad_input(t, what: str):
+    if isinstance(t, torch.Tensor) and t.requires_grad and torch.is_grad_enabled():
+        raise _lib.MiRenderError(
+            f"{what} requires grad, but the compositing / field kernels produce no gradient for it: on the reference's path "
+            "depths and rays never carry one (the jitter is data, z_samples is detached at nerf/render.py:141)")
+
+
+class _CompositeFn(torch.autograd.Function):
+    """raw_to_outputs (nerf/render.py:78-103): forward mi_composite, backward mi_composite_bwd -> dL/d(raw)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rays):
+        rgb, depth, acc, w = ops.composite(raw, z, rays, want_weights=True)
+        ctx.save_for_backward(raw.detach(), z.detach(), rays.detach())
+        ctx.set_materialize_grads(False)
+        return rgb, depth, acc, w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_acc, g_w):
+        raw, z, rays = ctx.saved_tensors
+        if all(g is None for g in (g_rgb, g_depth, g_acc, g_w)):
+            return None, None, None
+        dev = raw.device
+        raw32, z32, rays32 = (t.to(device=dev, dtype=torch.float32).contiguous() for t in (raw, z, rays))
+        return _composite_bwd(raw32, z32, rays32, g_rgb, g_depth, g_acc, g_w).to(raw.dtype).reshape(raw.shape), None, None
+
+
+def composite(raw, z, rays, want_weights: bool = True):
+    """ops.composite with autograd history towards `raw` (rgb[n,3], depth[n], acc[n], weights[n,S]|None)."""
+    _no_grad_input(z, "z_vals")
+    _no_grad_input(rays, "rays")
+    if not (torch.is_grad_enabled() and isinstance(raw, torch.Tensor) and raw.requires_grad):
+        return ops.composite(raw, z, rays, want_weights)
+    rgb, depth, acc, w = _CompositeFn.apply(raw, z, rays)
+    return rgb, depth, acc, (w if want_weights else None)
+
+
+class _FieldFn(torch.autograd.Function):
+    """network(inputs) of ONE pass for a fused kind - on rays (`z` [n,S]) or on free-standing points (`z` None, `rays` =
+    x [M,6]) - with gradients to its parameters and to the FiLM table: the saving forward / backward chain / dW GEMMs of
+    _RenderRaysFn, one pass at a time (a mixed pair's fused side; a fused module called on its own)."""
+
+    @staticmethod
+    def forward(ctx, pf, rays, z, film, *params):
+        raw, ctx.acts = _forward_pass(pf, rays, z, film, SAVE_FINE_BYTES)
+        ctx.pf, ctx.film, ctx.versions, ctx.points = pf, None if film is None else film.detach(), pf.versions(), z is None
+        ctx.save_for_backward(rays, raw) if z is None else ctx.save_for_backward(rays, raw, z)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        rays, raw = ctx.saved_tensors[:2]
+        z = None if ctx.points else ctx.saved_tensors[2]
+        pf = ctx.pf
+        if pf.versions() != ctx.versions:
+            raise RuntimeError("field backward: a field parameter was modified in place (or replaced) after the forward "
+                               "pass that this backward belongs to")
+        grads, g_film = _field_backward(pf, rays, z, raw, g_raw.to(torch.float32).contiguous(), ctx.film, ctx.acts)
+        ctx.acts = None
+        if g_film is not None:
+            g_film = g_film.reshape(ctx.film.shape) if ctx.needs_input_grad[3] else None
+        return (None, None, None, g_film) + tuple(grads)
+
+
+def _field_wants_grad(pf, film) -> bool:
+    return torch.is_grad_enabled() and (any(p.requires_grad for p in pf.params) or
+                                        (isinstance(film, torch.Tensor) and film.requires_grad))
+
+
+def field_eval_rays(pf, rays, z, film=None):
+    """ops.field_eval_rays (raw [n,S,4]) with autograd history towards the field's parameters and the FiLM table."""
+    _no_grad_input(z, "z_vals")
+    _no_grad_input(rays, "rays")
+    if not _field_wants_grad(pf, film):
+        return ops.field_eval_rays(pf, rays, z, film)
+    dev = pf.device
+    rays = rays.detach().to(device=dev, dtype=torch.float32).contiguous()
+    z = z.detach().to(device=dev, dtype=torch.float32).contiguous()
+    return _FieldFn.apply(pf, rays, z, film if fields.is_film(pf.kind) else None, *pf.params)
+
+
+def field_eval_points(pf, x, film=None):
+    """fields.eval_points (network(x [M,6]) -> [M,4], nerf/render.py:73) with autograd history towards the parameters and
+    the FiLM table.  No gradient with respect to x: nothing on the reference's path asks for one."""
+    _no_grad_input(x, "the field's input points")
+    if not _field_wants_grad(pf, film):
+        return fields.eval_points(pf, x, film)
+    if x.dim() != 2 or x.shape[1] != 6:
+        raise _lib.MiRenderError(f"expected inputs [M,6], got {tuple(x.shape)}")
+    x = x.detach().to(device=pf.device, dtype=torch.float32).contiguous()
+    if x.shape[0] == 0:
+        return fields.eval_points(pf, x, film) + sum(p.reshape(-1)[:1].sum() for p in pf.params if p.requires_grad) * 0.0
+    return _FieldFn.apply(pf, x, None, film if fields.is_film(pf.kind) else None, *pf.params).reshape(-1, 4)

@@ -92,18 +92,35 @@ def render_image_dist(width, height, focal, pose, near, far, coarse_model, fine_
     return render_image_sharded(shard, width, height, group, timing)
 
 
-def allreduce_grads(params, group=None):
+def allreduce_grads(params, group=None, timing: list | None = None):
     """Average renderer gradients over ranks in ONE flat all-reduce (4.75 MB for two NeRFs, 8.4 MB for the
-    pi_GAN generator: latency-bound on xGMI, so one bucket)."""
+    pi_GAN generator: latency-bound on xGMI, so one bucket).
+    Every parameter that requires grad takes part, a missing gradient as zeros (and receives the average): the flat
+    buffer then has the same layout on every rank whatever each rank's shard happened to touch - a rank whose shard is
+    empty, or whose loss did not reach one of the models, would otherwise reduce a shorter buffer and hang the others.
+    `timing`: a list that receives one (start, end) pair of torch.cuda.Event per call, recorded on the current stream
+    around flatten + all-reduce + scatter-back (bench.py reports the gradient exchange's cost from them)."""
     if not _exchange(group):
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
+    params = [p for p in params if p.requires_grad]
+    if not params:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    ev = None
+    if timing is not None and params[0].is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    flat = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat /= dist.get_world_size(group)
     off = 0
-    for g in grads:
-        g.copy_(flat[off:off + g.numel()].view_as(g))
-        off += g.numel()
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+    if ev is not None:
+        ev[1].record()
+        timing.append(ev)
+    return flat.numel() * flat.element_size()

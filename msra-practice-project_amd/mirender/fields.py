@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import warnings
 import weakref
 
 import numpy as np
@@ -262,8 +263,16 @@ def as_packed_field(model) -> PackedField | None:
         if not named and getattr(model, "_is_replica", False):
             named = _replica_named(model)
         kind = detect_kind(named)
-        if kind is not None and hyper_mismatch(model, kind) is not None:
-            kind = None            # same layout, other arithmetic (w_0 != 30, another activation): generic path
+        why = None if kind is None else hyper_mismatch(model, kind)
+        if why is not None:
+            # same layout, other arithmetic (w_0 != 30, another activation, layers that do not say): generic path - the
+            # module's own forward between the sampling / compositing kernels, correct but orders of magnitude slower
+            # than the fused kernels.  Said once per model (the verdict is cached and NOT re-checked if a layer's
+            # attributes change later: INTEGRATION.md)
+            warnings.warn(f"{type(model).__name__} has the parameter layout of {KIND_NAMES[kind]} but is not claimed by the "
+                          f"fused kernels ({why}); it is rendered through the generic path (its own forward)",
+                          RuntimeWarning, stacklevel=3)
+            kind = None
         if kind is None:
             _field_cache[model] = False
             return None
@@ -355,7 +364,8 @@ class _FusedField(torch.nn.Module):
         return FLOPS_PER_POINT[self.KIND]
 
     def forward(self, input_tensor):
-        return eval_points(as_packed_field(self), input_tensor)
+        from . import autograd          # gradients reach the parameters like the reference module's own forward
+        return autograd.field_eval_points(as_packed_field(self), input_tensor)
 
 
 def _xavier(w, gain):
@@ -435,7 +445,8 @@ class FilmSirenNeRF(_FusedField):
             self.film_params = film_params
         elif self.film_params is None:
             raise ValueError
-        return eval_points(as_packed_field(self), input_tensor, film_table(self))
+        from . import autograd          # ... and the FiLM parameters (pi_GAN/synthesis.py:83-107 optimises them directly)
+        return autograd.field_eval_points(as_packed_field(self), input_tensor, film_table(self))
 
 
 class FilmSirenNeRFNoDir(FilmSirenNeRF):

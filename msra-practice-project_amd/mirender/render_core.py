@@ -69,24 +69,40 @@ def run_network(ray_samples, view_dirs, network, chunk=1024 * 64):
     x = torch.cat([ray_samples.reshape(-1, 3), view_dirs[:, None].expand(n, s, 3).reshape(-1, 3)], -1)
     pf = fields.as_packed_field(network)
     if pf is not None and not fields.is_film(pf.kind):
-        out = fields.eval_points(pf, x)
+        from . import autograd
+        out = autograd.field_eval_points(pf, x)            # one launch; gradients reach the parameters like the reference's
     else:
         out = torch.cat([network(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)])
     return out.reshape(n, s, 4)
 
 
 def raw_to_outputs(raw, z_vals, rays_d):
-    """nerf/render.py:78-103 on the compositing kernel: (rgb, depth, acc, weights)."""
+    """nerf/render.py:78-103 on the compositing kernel: (rgb, depth, acc, weights), differentiable with respect to `raw`
+    like the reference's torch ops (backward: mi_composite_bwd).  `z_vals` / `rays_d` carry no gradient on the reference's
+    path (render.py:141 detaches the resampled depths); passing ones that require grad raises instead of dropping it."""
+    from . import autograd
     rays = torch.stack([torch.zeros_like(rays_d), rays_d], 1)
-    return ops.composite(raw, z_vals, rays, want_weights=True)
+    return autograd.composite(raw, z_vals, rays, want_weights=True)
 
 
 def _generic_field(network, rays, z, chunk=1024 * 64):
-    """Unknown callable: points/view dirs are formed with torch ops on the device and fed to it."""
+    """Unknown callable: points/view dirs are formed with torch ops on the device and fed to it; its own autograd graph
+    (parameters, FiLM leaves, whatever it closes over) reaches the returned raw values."""
     o, d = rays[:, 0], rays[:, 1]
     view = d / torch.norm(d, dim=-1, keepdim=True)
     pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
     return run_network(pts, view, network, chunk).to(torch.float32).contiguous()
+
+
+def _eval_pass(model, pf, rays, z, film):
+    """raw [n,S,4] of one pass on the generic path: a fused kind (one side of a mixed pair) through its own kernels with
+    gradients to its parameters / FiLM table, anything else through its own forward."""
+    if pf is None:
+        return _generic_field(model, rays, z)
+    from . import autograd
+    if fields.is_film(pf.kind) and film is None:
+        film = fields.film_table(model)
+    return autograd.field_eval_rays(pf, rays, z, film if fields.is_film(pf.kind) else None)
 
 
 def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fine_sample_num, *,
@@ -107,6 +123,13 @@ def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fi
         # off the parameters with zero gradients, so a loss over an empty shard still backpropagates
         outs = [torch.empty(s, dtype=torch.float32, device=dev) for s in ((0, 3), (0,), (0,), (0, 3), (0,), (0,))]
         leaves = [p for m in (coarse_model, fine_model) if isinstance(m, torch.nn.Module) for p in m.parameters() if p.requires_grad]
+        # ... and off the FiLM source (the mapping network's output, a GAN-inversion leaf): a rank with an empty shard must
+        # hand allreduce_grads the same set of gradients as every other rank
+        for m in (coarse_model, fine_model):
+            fp = film if film is not None else getattr(m, "film_params", None)
+            for t in ([fp] if isinstance(fp, torch.Tensor) else [x for pair in (fp or []) for x in pair]):
+                if isinstance(t, torch.Tensor) and t.requires_grad and not any(t is u for u in leaves):
+                    leaves.append(t)
         if torch.is_grad_enabled() and leaves:
             zero = sum(p.reshape(-1)[:1].sum() for p in leaves) * 0.0
             outs = [o + zero for o in outs]
@@ -124,16 +147,18 @@ def render_rays(rays, near, far, coarse_model, fine_model, coarse_sample_num, fi
             return autograd.render_rays_train(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0, ray0)
         return ops.render_rays_fused(pf_c, pf_f, rays, near, far, nc, nf, film, t_rand, seed or 0, ray0=ray0)
 
-    # generic path: sampling / compositing kernels around an arbitrary callable
+    # generic path: sampling / compositing kernels around an arbitrary callable (or a mixed pair: one fused kind, one
+    # callable).  Differentiable like the reference's torch ops (render.py:59-103): the callable's graph reaches `raw`,
+    # compositing continues it (autograd.composite -> mi_composite_bwd), a fused side goes through its own backward
+    # kernels (autograd.field_eval_rays); the resampled depths are detached as at render.py:141.
+    from . import autograd
     n = rays.shape[0]
     z_c = ops.sample_coarse(n, near, far, nc, dev, t_rand, seed or 0, ray0=ray0)
-    raw_c = ops.field_eval_rays(pf_c, rays, z_c) if pf_c is not None and not fields.is_film(pf_c.kind) \
-        else _generic_field(coarse_model, rays, z_c)
-    rgb_c, depth_c, acc_c, w_c = ops.composite(raw_c, z_c, rays)
-    z_f = ops.sample_fine(z_c, w_c, near, far, nf)
-    raw_f = ops.field_eval_rays(pf_f, rays, z_f) if pf_f is not None and not fields.is_film(pf_f.kind) \
-        else _generic_field(fine_model, rays, z_f)
-    rgb_f, depth_f, acc_f, _ = ops.composite(raw_f, z_f, rays, want_weights=False)
+    raw_c = _eval_pass(coarse_model, pf_c, rays, z_c, film)
+    rgb_c, depth_c, acc_c, w_c = autograd.composite(raw_c, z_c, rays)
+    z_f = ops.sample_fine(z_c, w_c.detach(), near, far, nf)
+    raw_f = _eval_pass(fine_model, pf_f, rays, z_f, film)
+    rgb_f, depth_f, acc_f, _ = autograd.composite(raw_f, z_f, rays, want_weights=False)
     return rgb_c, depth_c, acc_c, rgb_f, depth_f, acc_f
 
 

@@ -2,8 +2,8 @@
 
 Only tests/ and __graft_entry__.smoke() import this.  Every check appends one record - case, stage, quantity,
 achieved max |err| against the fp32 oracle (and against its fp64 evaluation where one was made), the gate and WHICH
-bound was the active one - and the pytest session writes them to gpurun_out/r03_parity.json (committed copy:
-profiles/r03_parity.json).
+bound was the active one - and the pytest session writes them to gpurun_out/r04_parity.json (committed copy of the round:
+profiles/r04_parity.json).
 
 Gates (BASELINE.json north_star: "within 1e-4 abs on fixed seeds"):
 

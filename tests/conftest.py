@@ -44,9 +44,9 @@ def golden():
 
 def pytest_sessionfinish(session, exitstatus):
     """Every parity check leaves a record (oracle/parity.py): achieved error, gate, which bound was active.  The GPU
-    session writes them under gpurun_out/ (merged back by gpurun); the committed copy is profiles/r03_parity.json."""
+    session writes them under gpurun_out/ (merged back by gpurun); the committed copy is profiles/r04_parity.json (one per round)."""
     from oracle import parity
-    out = os.environ.get("MI_PARITY_JSON", os.path.join(ROOT, "gpurun_out", "r03_parity.json"))
+    out = os.environ.get("MI_PARITY_JSON", os.path.join(ROOT, "gpurun_out", "r04_parity.json"))
     try:
         parity.write_records(out)
     except Exception as e:      # noqa: BLE001  (bookkeeping must never turn a green run red or hide a red one)

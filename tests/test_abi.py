@@ -36,7 +36,7 @@ def test_binding_table_matches_header():
     _lib = ensure_built()
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
-    assert lib.mi_abi_version() == 3
+    assert lib.mi_abi_version() == 4
 
 
 def test_size_queries_need_no_gpu():

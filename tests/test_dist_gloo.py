@@ -50,7 +50,13 @@ def _worker(rank, world, port, out, w=W, h=H):
     p = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7))]
     for q in p:
         q.grad = torch.full_like(q, float(rank + 1))
+    # a parameter only the even ranks' shards reached (an empty shard, a loss that touched one model only): it still takes
+    # part on every rank, as zeros where it is missing - the flat buffers must have ONE layout or the collective hangs
+    p.append(torch.nn.Parameter(torch.zeros(4)))
+    if rank % 2 == 0:
+        p[-1].grad = torch.full((4,), float(rank + 1))
     mdist.allreduce_grads(p)
+    assert p[-1].grad is not None
     out[rank] = (rgb.numpy(), depth.numpy(), acc.numpy(), [q.grad.clone().numpy() for q in p])
     dist.destroy_process_group()
 
@@ -67,7 +73,7 @@ def test_sharded_frame_equals_single_process():
         assert rgb.shape == (H, W, 3) and depth.shape == (H, W, 1) and acc.shape == (H, W, 1)
         assert np.array_equal(rgb.reshape(-1, 3), ref[0].numpy())     # shards are independent: exact
         assert np.array_equal(depth.reshape(-1), ref[1].numpy()) and np.array_equal(acc.reshape(-1), ref[2].numpy())
-        assert all(np.allclose(g, 1.5) for g in grads)
+        assert all(np.allclose(g, 1.5) for g in grads[:2]) and np.allclose(grads[2], 0.5)
 
 
 @pytest.mark.timeout(600)
@@ -102,7 +108,8 @@ def test_eight_ranks_ragged_and_empty_shards(w, h):
         assert rgb.shape == (h, w, 3) and depth.shape == (h, w, 1) and acc.shape == (h, w, 1)
         assert np.array_equal(rgb.reshape(-1, 3), ref[0])
         assert np.array_equal(depth.reshape(-1), ref[1]) and np.array_equal(acc.reshape(-1), ref[2])
-        assert all(np.allclose(g, 4.5) for g in grads)                 # mean of 1..8
+        assert all(np.allclose(g, 4.5) for g in grads[:2])             # mean of 1..8
+        assert np.allclose(grads[2], 2.0)                               # (1 + 3 + 5 + 7) / 8: the odd ranks sent zeros
 
 
 def _one_rank_worker(rank, world, port, out):
