@@ -19,10 +19,12 @@ Extra objects in the line:
   cpu_baseline  the CPU oracle (oracle/render_ref.py, PyTorch CPU, all host cores) on a bounded sample of
                 the same workload, rank 0, N=1 only; with it `psnr_vs_ref`: held-out-view PSNR of a TinyNeRF fitted
                 to a synthetic teacher scene by the HIP path and by the reference loop on the CPU (oracle/fit_ref.py)
-  train         N=1 only: the secondary training workloads (nerf 1024-ray step x40, pi_GAN C4 step x3).  pi_GAN passes ONE
-                field as coarse and fine model, so the renderer evaluates the fine pass's Nf new depths only:
-                `frac_of_fp32_mfma_peak` keeps SURVEY.md 8d's count of what the reference executes (120 evaluations per
-                ray), `frac_executed` counts what this renderer executes (108) - the one to hold against MFMA-busy
+  train         every N: the secondary training workloads, data-parallel (weak scaling) with one flat RCCL gradient all-reduce
+                per step, timed on its own: nerf 1024-rays-per-GPU step x40, pi_GAN C5 step (4 images 256x256 per GPU, D-step
+                forward + G-step) x3; N=1 also the C4 step x3.  pi_GAN passes ONE field as coarse and fine model, so the
+                renderer evaluates the fine pass's Nf new depths only: `frac` / `frac_executed` count what
+                this renderer executes (C4: 108 evaluation-equivalents per ray) - the figure to hold against MFMA-busy -
+                and `frac_reference_equivalent` SURVEY.md 8d's count of what the reference executes (120)
   collective    N>1 (or --force-collective): ranks seen by torch.distributed, per-rank mean MLP launch time,
                 all-gather time per frame
 """
@@ -169,6 +171,7 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
       nerf_train  nerf/train_nerf.py step: 1024 rays per GPU, 64+128 samples, coarse+fine NeRF, Adam"""
     from mirender import dist as mdist, fields, pigan, render_core, train
     torch.manual_seed(rank)
+    reduce_events, timed = [], [False]       # (start, end) stream events around every timed step's gradient all-reduce
     workload = workload or args.workload
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
@@ -178,6 +181,9 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         # GPUs), Nc=24 Nf=48, one whole training step = the D-step's generator forward (no grad, pi_GAN/train.py:108-111)
         # + the G-step forward/backward; the discriminator itself is stock PyTorch and not timed here.
         res, b, nc, nf = (256, 4, 24, 48) if c5 else (128, 32, 12, 24)
+        shrunk = os.environ.get("MI_BENCH_REHEARSAL") == "1" and world > 2
+        if shrunk:                  # rehearsal with several ranks on ONE device: a full-size step per rank would not fit it
+            res = 64
         gen = pigan.Generator(256, res, near=0.5, far=1.5, fov=12, coarse_samples=nc, fine_samples=nf).to(dev)
         params = list(gen.parameters())
         opt = torch.optim.Adam(params, lr=5e-5, betas=(0.0, 0.9))
@@ -200,11 +206,13 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
             loss = torch.nn.functional.softplus(-img.mean(dim=(1, 2, 3))).mean()   # stand-in for -D(G(z))
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            mdist.allreduce_grads(params)
+            mdist.allreduce_grads(params, timing=reduce_events if timed[0] else None)
             opt.step()
-        name = ("pi_GAN training step 256x256, batch 4/GPU, 24+48 samples (BASELINE config C5): D-step generator forward "
+        name = (f"pi_GAN training step {res}x{res}, batch 4/GPU, 24+48 samples (BASELINE config C5): D-step generator forward "
                 "+ G-step fwd+bwd+Adam, RCCL grad all-reduce" if c5 else
                 "pi_GAN generator training step 128x128, batch 32/GPU, 12+24 samples (BASELINE config C4), fwd+bwd+Adam")
+        if shrunk:
+            name += " [REHEARSAL: images shrunk from 256x256 so that every rank's step fits the one shared device]"
     else:
         n, nc, nf = 1024, 64, 128
         coarse, fine = make_models(dev)
@@ -224,7 +232,7 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
             loss, _psnr = train.nerf_loss(outs, tgt[:, :3], tgt[:, 3], use_alpha=True, use_fine_model=True)  # train_nerf.py:158-167
             opt.zero_grad(set_to_none=True)
             loss.backward()
-            mdist.allreduce_grads(params)
+            mdist.allreduce_grads(params, timing=reduce_events if timed[0] else None)
             opt.step()
         name = "nerf/train_nerf.py step: 1024 rays/GPU, 64+128 samples, coarse+fine NeRF 8x256, fwd+bwd+fused Adam"
 
@@ -241,23 +249,38 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
     for i in range(settle + warmup):
         step(i)
     sync()
+    timed[0] = True
     t0 = time.perf_counter()
     for i in range(steps):
         step(settle + warmup + i)
     sync()
-    elapsed = time.perf_counter() - t0
+    mine_s = elapsed = time.perf_counter() - t0
+    timed[0] = False
+    per_rank_step_ms, per_rank_reduce_ms = [mine_s / steps * 1e3], [None]
+    if reduce_events:
+        per_rank_reduce_ms = [sum(a.elapsed_time(b) for a, b in reduce_events) / len(reduce_events)]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    achieved = flops * steps / elapsed / 1e12
+        mine = torch.tensor([per_rank_step_ms[0], per_rank_reduce_ms[0] or 0.0], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_step_ms, per_rank_reduce_ms = [float(t[0]) for t in allr], [float(t[1]) for t in allr]
+    # What the GPUs executed: `achieved` / `frac` count the evaluations this renderer really runs - the figure
+    # comparable to the MFMA-busy counters.  SURVEY.md 8d's count of what the REFERENCE executes (it evaluates the Nc coarse
+    # points a second time in the fine pass) is carried next to it under an explicit name.
+    achieved_ref = flops * steps / elapsed / 1e12                         # per GPU: every rank runs its own `flops` per step
+    achieved = achieved_ref * evals_executed / evals
     # HBM bytes per step: not measurable from inside the process; from the committed rocprofv3 PMC passes of this same
-    # workload (profiles/r02_pmc_<workload>.json: WRITE_SIZE + 2 x FETCH_SIZE summed over every kernel of the two traced
-    # steps, tools/summarise_pmc.py).  null if absent.
+    # workload (profiles/rNN_pmc_<workload>.json: WRITE_SIZE + 2 x FETCH_SIZE summed over every kernel of the traced run,
+    # tools/summarise_pmc.py) divided by the number of steps that run traced - its --steps 1 --warmup 1 plus, for the
+    # pi_GAN workloads, the two allocator-settle steps.  null if absent.
     traffic, pmc_path = None, newest_profile(f"pmc_{workload}.json")
     try:
         pmc = json.load(open(pmc_path))
-        traffic = sum(k["hbm_bytes_2xFETCH_plus_WRITE"] for k in pmc["kernels"].values()) / 2
+        traced = pmc.get("steps_traced", 2 + settle)
+        traffic = sum(k["hbm_bytes_2xFETCH_plus_WRITE"] for k in pmc["kernels"].values()) / traced
     except (OSError, KeyError, ValueError, TypeError):
         pass
     pmc_name = os.path.basename(pmc_path) if pmc_path else None
@@ -268,22 +291,31 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         extra["nerf_train_global_batch"] = world * rays_per_step
     return {
         "metric": "rays/sec (training step)", "value": world * rays_per_step * steps / elapsed, "unit": "rays/s",
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "n_gpus": world, "steps": steps, "warmup": settle + warmup, "untimed_steps": settle + warmup,
+        "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step, "allocator_settle_steps": settle, **extra,
+        "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step, "allocator_settle_steps": settle,
+                   "warmup_requested": warmup, **extra,
                    "parallelism": (f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU")
                    + (" [REHEARSAL: all ranks on one device, gloo]" if os.environ.get("MI_BENCH_REHEARSAL") == "1" else "")},
         "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                        "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
-                       "grad_allreduce_bytes": int(sum(p.numel() for p in params) * 4),
-                       "note": "one flat all_reduce of the renderer gradients per step (mirender.dist.allreduce_grads)"},
+                       "grad_allreduce_bytes": int(sum(p.numel() for p in params if p.requires_grad) * 4),
+                       "per_rank_ms_per_step": per_rank_step_ms, "per_rank_grad_allreduce_ms": per_rank_reduce_ms,
+                       "note": "one flat all_reduce of the renderer gradients per step (mirender.dist.allreduce_grads); its "
+                               "time is from stream events around flatten + all_reduce + scatter-back in every timed step "
+                               "(null with one rank and no forced collective: nothing is exchanged)"},
         "roofline": {"bound": "mfma", "kernel": "whole training step (forward, backward chain, dW GEMMs)",
                      "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                     "evals_per_ray_algorithmic": evals, "evals_per_ray_executed": evals_executed,
-                     "frac_executed": achieved * evals_executed / evals / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "per": "GPU",
+                     "evals_per_ray_executed": evals_executed, "evals_per_ray_reference": evals,
+                     "frac_executed": achieved / PEAK_FP32_MFMA_TFLOPS,
+                     "achieved_reference_equivalent": achieved_ref,
+                     "frac_reference_equivalent": achieved_ref / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "traffic_unit": f"HBM bytes per step (PMC, profiles/{pmc_name})",
-                     "note": "algorithmic FLOPs = 2 x MACs x (1 per no-grad pass + 3 per trained pass), SURVEY.md 8d"},
+                     "note": "FLOPs = 2 x MACs x evaluations EXECUTED (1 per no-grad pass + 3 per trained pass over the points "
+                             "this renderer evaluates); *_reference_equivalent counts the reference's evaluations (SURVEY.md 8d: "
+                             "it evaluates the coarse points again in the fine pass)"},
     }
 
 
@@ -291,15 +323,18 @@ def psnr_vs_ref(dev):
     """The metric's "PSNR vs ref" clause on trained results: student pairs fitted to the synthetic teacher scene of
     oracle/fit_ref.py (24x24 views, 16+16 samples, the loop of nerf/train_nerf.py:124-176) by the HIP path and by the same
     loop on the CPU - same initial weights, rays and jitter; held-out-view PSNR of both.  TinyNeRF (PE + ReLU): 60 Adam
-    steps of 256 rays at 5e-4, CPU side = the oracle's loop run here; SirenNeRF and FilmSirenNeRF (fixed FiLM row): 15 Adam steps over all
-    3 456 rays at 1e-5, CPU side = the REFERENCE's own code run in the build container (tests/golden/fit_r03_siren_adam.npz:
-    a live CPU fit of an 8x256 sin pair costs ~2 minutes on this host).  Both regimes are reproducible under a 1e-6
+    steps of 256 rays at 5e-4, CPU side = the oracle's loop run here; NeRF 8x256 (the headline class, nerf/nerf.py:52-94): 20 Adam
+    steps over all 3 456 rays at train_nerf.py:98's 5e-4; SirenNeRF and FilmSirenNeRF (fixed FiLM row): 15 Adam steps over all
+    3 456 rays at 1e-5 - for these three the CPU side = the REFERENCE's own code run in the build container
+    (tests/golden/fit_r04_nerf_adam.npz, fit_r03_siren_adam.npz, fit_r03_film_adam.npz: a live CPU fit of an 8x256 pair costs
+    1-2 minutes on this host).  Both regimes are reproducible under a 1e-6
     perturbation of the initial weights to < 1e-3 dB (tests/test_gpu_psnr.py gates them hard).  Part of the CPU-baseline
     leg (the only place bench.py touches oracle/)."""
     from mirender import fields, render_core
     from oracle import fit_ref, render_ref as R
     out = {}
-    for student, lr0, batch, steps, fixture in (("tiny_nerf", 5e-4, 256, 60, None), ("siren_nerf", 1e-5, 0, 15, "fit_r03_siren_adam"),
+    for student, lr0, batch, steps, fixture in (("tiny_nerf", 5e-4, 256, 60, None), ("nerf", 5e-4, 0, 20, "fit_r04_nerf_adam"),
+                                                 ("siren_nerf", 1e-5, 0, 15, "fit_r03_siren_adam"),
                                                  ("film_siren_nerf", 1e-5, 0, 15, "fit_r03_film_adam")):
         images = None
         if fixture is not None:             # the reference run fitted the teacher views as the build container rendered them
@@ -505,22 +540,35 @@ def main():
                       "note": "one all_gather_into_tensor of packed [n_local, 5] fp32 per frame, issued after the last "
                               "composite kernel (no overlap: the frame is not complete before that)"}
 
-    # N=1 only: the secondary training workloads inside this (driver-timed) run, after the frame's workspace is freed
+    # The secondary training workloads inside this (driver-timed) run, after the frame's workspace is freed - at EVERY N, so
+    # that the driver's own 1/2/4/8-GPU command also times what BASELINE.json's north_star asks of 8 GPUs: the pi_GAN
+    # 256x256 training step (config C5: 4 images per GPU, D-step forward + G-step) and the nerf 1024-rays-per-GPU step, both
+    # data-parallel with ONE flat RCCL all-reduce of the renderer gradients per step (pi_GAN/train.py:50,52's DataParallel
+    # replaced), the all-reduce timed on its own.  Weak scaling (per-GPU work fixed): efficiency = ms_per_step(1) / ms_per_step(N).
+    # C4 (batch 32 on one GPU) is a single-GPU configuration and stays at N = 1.
     train = None
-    if world == 1 and not args.no_train:
+    if not args.no_train:
         del out
         from mirender import ops
         ops._Workspace.release()
         torch.cuda.empty_cache()
         train = {}
-        # (steps, warm-up): the 7.6 ms nerf step needs a few steps for the allocator to settle; C4 is 0.56 s a step
-        for wl, (k, w) in (("nerf_train", (40, 8)), ("c4", (3, 1))):
+        # (steps, warm-up): the 7 ms nerf step needs a few steps for the allocator to settle; C4 / C5 are 0.5 - 0.6 s a step
+        # (+ two allocator-settle steps inside train_workload)
+        plan = [("nerf_train", (40, 8)), ("c5", (3, 1))] + ([("c4", (3, 1))] if world == 1 else [])
+        for wl, (k, w) in plan:
             r = train_workload(args, world, rank, dev, workload=wl, steps=k, warmup=w)
             train[wl] = {"rays_per_s": r["value"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                         "untimed_steps": r["untimed_steps"], "scaling": "weak",
                          "n_ranks_seen": r["collective"]["n_ranks_seen"],
-                         "tflops": r["roofline"]["achieved"], "frac_of_fp32_mfma_peak": r["roofline"]["frac"],
+                         "per_rank_ms_per_step": r["collective"]["per_rank_ms_per_step"],
+                         "per_rank_grad_allreduce_ms": r["collective"]["per_rank_grad_allreduce_ms"],
+                         "grad_allreduce_bytes": r["collective"]["grad_allreduce_bytes"],
+                         "tflops_per_gpu": r["roofline"]["achieved"], "frac": r["roofline"]["frac"],
                          "frac_executed": r["roofline"]["frac_executed"],
-                         "evals_per_ray": [r["roofline"]["evals_per_ray_algorithmic"], r["roofline"]["evals_per_ray_executed"]],
+                         "frac_reference_equivalent": r["roofline"]["frac_reference_equivalent"],
+                         "evals_per_ray": {"executed": r["roofline"]["evals_per_ray_executed"],
+                                           "reference": r["roofline"]["evals_per_ray_reference"]},
                          "workload": r["config"]["workload"]}
             torch.cuda.empty_cache()
 

@@ -19,6 +19,8 @@
 
 #include "field_mlp_device.h"
 
+#include <type_traits>
+
 namespace mi {
 
 __constant__ PackTable c_tabb_nerf = build_nerf_bwd();
@@ -100,6 +102,18 @@ struct BwdArgs {
 unsigned long long* g_bwd_stamps = nullptr;       // set by mi_debug_set_stamps (api.hip), diagnostic build only
 #endif
 
+// f32x4 element i of a lane's row in a [point][width] region: a UNIFORM base pointer (SGPR pair) + one per-lane 32-bit
+// byte offset (+ 16 i as the instruction's immediate) - the `global_load/store v, v_off, s[base:base+1] offset:imm` form.
+template <class V>
+struct RowRef {
+    using Byte = std::conditional_t<std::is_const_v<V>, const char, char>;
+    Byte* base;
+    uint32_t off;
+    __device__ __forceinline__ V& operator[](int i) const {
+        return *reinterpret_cast<V*>(base + (uint64_t)off + (uint64_t)((uint32_t)i * 16u));
+    }
+};
+
 // The saved row of the chain's first epilogue (the 128-wide dir layer), loaded at the top of the kernel: its latency
 // overlaps the first weight stage's DMA and the head gradients instead of following them.
 template <int MB>
@@ -166,12 +180,22 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
     static_assert(KB != 8 || MB == 8, "the 8-K-block slot mapping below counts on 24 mid slots per K block (MB = 8)");
     static_assert(!(DEFER && EPI == EPI_FILM), "FiLM layers store dL/du, not what they carry on");
     const int h = c.h;
-    const lds4_t pv = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
+    // only SCALED layers read the start row: lds_base's opaque asm would otherwise keep a dead address alive across a
+    // layer loop (the SirenNeRF chain spilled and reloaded exactly that, once per layer, in front of a stage barrier)
+    lds4_t pv = nullptr;
+    if constexpr (SCALED) pv = lds_base(c.smem + kLdsAux0 + aux_slot * kLdsAux + h * 16);
     lds4_t pg = nullptr;
     if constexpr (EPI == EPI_FILM) pg = lds_base(film_row + h * 4);
-    const f32x4* srow = reinterpret_cast<const f32x4*>(saved + p * ld + 4 * h);
-    f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
-    f32x4* prow = reinterpret_cast<f32x4*>(prev_dA + p * prev_ld + 4 * h);
+    // Row addresses as a UNIFORM base (the tile's first point: SGPRs) plus one 32-bit byte offset per lane (the lane's
+    // point inside the tile: < 128 rows), so a row instruction is `global_load/store ..., v_off, s[base]` and the three
+    // row pointers of a layer cost one VGPR, not three 64-bit pairs: round 4 - the SirenNeRF chain kept its per-lane
+    // 64-bit row pointers across the layer loop in scratch (6 spilled registers, 3 reloads per layer, each followed by an
+    // s_waitcnt vmcnt(0) that drains the wave's row traffic).
+    const int64_t tile0 = (int64_t)blockIdx.x * 128;
+    const uint32_t lrow = (uint32_t)(p - tile0);
+    const RowRef<const f32x4> srow{reinterpret_cast<const char*>(saved + tile0 * ld), (lrow * (uint32_t)ld + 4u * h) * 4u};
+    const RowRef<f32x4> drow{reinterpret_cast<char*>(dA + tile0 * ld), (lrow * (uint32_t)ld + 4u * h) * 4u};
+    const RowRef<f32x4> prow{reinterpret_cast<char*>(prev_dA + tile0 * prev_ld), (lrow * (uint32_t)prev_ld + 4u * h) * 4u};
     f32x4 sv[EPI == EPI_LINEAR ? 1 : MB * 4];
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;

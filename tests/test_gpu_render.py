@@ -501,6 +501,19 @@ def test_no_rays_is_a_valid_input(nerf_render):
     out = render_core.render_rays(rays, 2.0, 6.0, cm, fm, 8, 8)
     (out[3].sum() + out[0].sum()).backward()
     assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in list(cm.parameters()) + list(fm.parameters()))
+    # a FiLM field with a trainable FiLM source (the mapping network's output, a GAN-inversion leaf): it too gets a zero
+    # gradient from an empty shard, whether it came in as `film=` or as the module's own film_params (a
+    # rank with no rays must hand allreduce_grads the same set of gradients as the others)
+    fm_film = model("film_siren_nerf", synth.state_dict("film_siren_nerf", seed=7))
+    film = synth.film_params(1, seed=4).to(dev()).requires_grad_(True)
+    out = render_core.render_rays(rays, 0.5, 1.5, fm_film, fm_film, 8, 8, film=film)
+    out[3].sum().backward()
+    assert film.grad is not None and float(film.grad.abs().max()) == 0.0
+    leaf = synth.film_params(1, seed=4)[0].to(dev()).requires_grad_(True)
+    fm_film.set_film_params(leaf)
+    out = render_core.render_rays(rays, 0.5, 1.5, fm_film, fm_film, 8, 8)
+    out[3].sum().backward()
+    assert leaf.grad is not None and float(leaf.grad.abs().max()) == 0.0
     part = render_core._render_image_device(16, 16, 22.2, synth.pose_degrees(4.0, 0.0, -30.0), 2.0, 6.0, cm, fm, 8, 8, None, None, 3, 40, 0)
     assert [tuple(o.shape) for o in part] == [(0, 3), (0,), (0,)]
     lib = _lib.load()

@@ -91,11 +91,13 @@ def test_nerf_loss_grads_golden(golden):
                for rgb, acc in ((rgb_f, acc_f), (rgb_c, acc_c)))
     loss.backward()
     assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-4
-    # coarse gradients do not depend on the ill-conditioned resampling: tight; fine: the fp32 oracle's
-    # resampled depths differ on a few rays, so the gate is looser (relative to each tensor's norm)
+    # coarse gradients do not depend on the ill-conditioned resampling: tight (achieved 4.6e-5 of a tensor's norm); fine: the
+    # reference's resampled depths differ from the HIP path's on a few rays (the x50 head: DESIGN.md section 2), which moves a
+    # tensor's gradient by up to 9.4e-4 of its norm (fine.layers_pos.2.bias; profiles/r04_parity.json) - gated at 5e-3,
+    # ~5x that (round 3 had 2e-2 here: a 10x regression of the backward through resampling would have passed)
     case = f"F7 nerf loss gradients, 48 rays {nc}+{nf}, sharp heads (end to end through resampling)"
     _grad_check(case, [(k, p.grad) for k, p in cm.named_parameters()], g, "coarse.", tol=5e-4)
-    _grad_check(case, [(k, p.grad) for k, p in fm.named_parameters()], g, "fine.", tol=2e-2)
+    _grad_check(case, [(k, p.grad) for k, p in fm.named_parameters()], g, "fine.", tol=5e-3)
 
 
 @pytest.mark.parametrize("kind,n,nc,nf,sharp", [("nerf", 37, 16, 24, True), ("tiny_nerf", 130, 8, 8, True),
@@ -189,8 +191,10 @@ def test_pigan_image_and_grads_golden(golden):
     assert float((d > 1e-4).double().mean()) <= 0.05
     (img * torch.from_numpy(g["cotangent"]).to(dev())).sum().backward()
     case = f"F6 pi_GAN image gradients, 2 images {res}x{res} {nc}+{nf}, sharp head (end to end through resampling)"
-    parity.gate_grad(case, "film table", film.grad.cpu(), g["grad_film"], tol=5e-2)
-    _grad_check(case, [(k, p.grad) for k, p in m.named_parameters()], g, "", tol=5e-2)
+    # end to end through the resampling of a x50 head: achieved 2.4e-4 (FiLM table) and at worst 1.1e-3 of a tensor's norm
+    # (output_layer_sigma.0.bias); gated at 2e-3 / 5e-3 (round 3: 5e-2 for both)
+    parity.gate_grad(case, "film table", film.grad.cpu(), g["grad_film"], tol=2e-3)
+    _grad_check(case, [(k, p.grad) for k, p in m.named_parameters()], g, "", tol=5e-3)
 
 
 def test_shared_model_and_unused_outputs():
@@ -302,10 +306,16 @@ def test_partial_save_and_recompute_give_the_same_gradients(kind, monkeypatch):
         assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(a.abs().max()))
 
 
-def test_out_of_memory_in_backward_falls_back_to_recompute(monkeypatch):
+@pytest.mark.parametrize("fail_at", [3, 4])
+def test_out_of_memory_in_backward_falls_back_to_recompute(monkeypatch, fail_at):
     """the forward's save budget is an estimate of what the allocator can still give; if backward cannot
     allocate a range's gradient rows next to the kept layer inputs, it gives the remaining kept inputs back and
-    recomputes them (same gradients bit for bit) instead of failing in the middle of the pass."""
+    recomputes them (same gradients bit for bit) instead of failing in the middle of the pass.
+    fail_at = 3: the second range's FIRST allocation fails.  fail_at = 4: its SECOND one does, i.e. the
+    range's gradient rows had already been allocated - the retry must start with them released (it runs outside the
+    `except` block: inside it the exception's traceback would keep the failed call's frame, and those rows, alive exactly
+    when memory is shortest)."""
+    import weakref
     from mirender import autograd, fields, render_core
     m = fields.field_from_state_dict(synth.state_dict("film_siren_nerf", seed=34), dev())
     film = synth.film_params(4, seed=3).to(dev()).requires_grad_(True)
@@ -313,14 +323,19 @@ def test_out_of_memory_in_backward_falls_back_to_recompute(monkeypatch):
     rays = torch.from_numpy(R.rays_from_camera(24, 16, 33.3, synth.pose_degrees(1.0, 20.0, -30.0))[:n]).to(dev())
     tr = synth.t_rand(n, nc, seed=6).to(dev())
     monkeypatch.setattr(autograd, "_max_points_per_chunk", lambda pf: 96 * (nc + nf))      # 4 ranges, all kept
-    results, real, calls = [], autograd._guarded, {"n": 0, "raised": 0}
+    results, real, calls = [], autograd._guarded, {"n": 0, "raised": 0, "rows": None, "rows_alive_at_retry": None}
 
     def flaky(nfloats, d):
         calls["n"] += 1
-        if calls["armed"] and calls["n"] == 3:               # the second range's first allocation
+        if calls["armed"] and calls["n"] == fail_at:
             calls["raised"] += 1
             raise torch.cuda.OutOfMemoryError("injected by the test")
-        return real(nfloats, d)
+        if calls["armed"] and calls["n"] == fail_at + 1:     # the retry's first allocation
+            calls["rows_alive_at_retry"] = calls["rows"] is not None and calls["rows"]() is not None
+        out = real(nfloats, d)
+        if calls["armed"] and calls["n"] == 3:               # the second range's gradient rows
+            calls["rows"] = weakref.ref(out[0])
+        return out
     monkeypatch.setattr(autograd, "_guarded", flaky)
     for armed in (False, True):
         calls.update(n=0, armed=False)
@@ -332,6 +347,8 @@ def test_out_of_memory_in_backward_falls_back_to_recompute(monkeypatch):
         out[3].square().mean().backward()
         results.append([p.grad.clone() for p in m.parameters()] + [film.grad.clone()])
     assert calls["raised"] == 1
+    if fail_at == 4:
+        assert calls["rows_alive_at_retry"] is False          # the failed attempt's rows were released before the retry
     for a, b in zip(*results):
         assert torch.equal(a, b)
 

@@ -263,7 +263,8 @@ def test_fit_trajectory_fixtures_are_reproduced_by_the_oracle_loop(golden):
     oracle_loop_max_rel_loss_diff = 0); here, on whatever CPU runs this suite, the first two steps of the cheapest
     regime are replayed (forward, gradients, one SGD update - ~10 s) and the stored figures are checked for sanity."""
     from oracle import fit_ref, synth
-    for name in ("fit_r03_siren_adam", "fit_r03_film_adam", "fit_r03_siren_sgd", "fit_r03_film_sgd", "fit_r03_siren_chaotic"):
+    for name in ("fit_r03_siren_adam", "fit_r03_film_adam", "fit_r03_siren_sgd", "fit_r03_film_sgd", "fit_r03_siren_chaotic",
+                 "fit_r04_nerf_adam", "fit_r04_nerf_sgd"):      # r04: the headline NeRF class (nerf/nerf.py:52-94), --only-r04-fit
         g = golden(name)
         assert g["losses"].shape == (int(g["steps"]),) and g["heldout_rgb"].shape == (24 * 24, 3)
         assert float(g["oracle_loop_max_rel_loss_diff"]) <= (1.0 if name.endswith("chaotic") else 1e-4)
@@ -276,3 +277,9 @@ def test_fit_trajectory_fixtures_are_reproduced_by_the_oracle_loop(golden):
     assert synth.digest(scene.student_init[0]) == str(g["digest_c"])
     losses, _, _ = fit_ref.fit_cpu(scene, 2, 0, lr0=float(g["lr0"]), optimizer="sgd")
     assert np.abs(np.array(losses) - g["losses"][:2]).max() <= 1e-5 * g["losses"][0]
+    # ... and of the NeRF class's SGD run (PE + ReLU + skip: another host's MKL may flip a ReLU switch or two - 1e-4)
+    g = golden("fit_r04_nerf_sgd")
+    scene = fit_ref.Scene(student="nerf", images=golden("fit_r03_scene")["images"])
+    assert synth.digest(scene.student_init[0]) == str(g["digest_c"]) and synth.digest(scene.student_init[1]) == str(g["digest_f"])
+    losses, _, _ = fit_ref.fit_cpu(scene, 2, 0, lr0=float(g["lr0"]), optimizer="sgd")
+    assert np.abs(np.array(losses) - g["losses"][:2]).max() <= 1e-4 * g["losses"][0]

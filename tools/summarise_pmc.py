@@ -108,8 +108,15 @@ def train_summary(wl):
         if line:
             open(os.path.join(out_dir, f"{tag}_bench_{wl}.log"), "w").write(line[-1])
     if out:
+        settle = 2 if wl in ("c4", "c5") else 0       # bench.py's allocator-settle steps run traced too
+        steps_traced = settle + 1 + 1
+        for row in out.values():
+            row["hbm_bytes_per_step"] = row["hbm_bytes_2xFETCH_plus_WRITE"] / steps_traced
         json.dump({"command": f"rocprofv3 --pmc <group> --kernel-trace -- python3 bench.py --workload {wl} --steps 1 --warmup 1 "
-                              "(one pass per counter group; sums over the warm-up and the timed step)",
+                              f"(one pass per counter group; sums over every step that runs traced: {settle} allocator-settle "
+                              "+ 1 warm-up + 1 timed)",
+                   "steps_traced": steps_traced,
+                   "hbm_bytes_per_step": sum(r["hbm_bytes_per_step"] for r in out.values()),
                    "note": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH doubled for gfx950 (MI355X_MICROARCH.md)", "kernels": out},
                   open(os.path.join(out_dir, f"{tag}_pmc_{wl}.json"), "w"), indent=1)
         top = sorted(out.items(), key=lambda kv: -kv[1]["ms"])[:6]
