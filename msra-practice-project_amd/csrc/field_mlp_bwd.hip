@@ -693,10 +693,20 @@ struct GemmBatch {
 // LDS floats one k-split wave parks for the merge (its 4 x CB accumulator blocks + the bias sums), and the dynamic LDS a
 // launch needs: the two stage buffers, or the merge area of the (KS - 1) x TILES parked waves if that is larger.
 constexpr int gemm_merge_wave_floats(int CB) { return (4 * CB * 16 + 4) * 64; }
+// Stage buffers in the ring.  A 256x256 tile runs 256 MFMAs per wave and stage (6.9 us) on 64 KiB of rows: one stage in
+// flight while the other is consumed hides the memory latency, and two buffers are all that fit.  The NARROW tiles run 16 -
+// 128 MFMAs (0.4 - 3.4 us) on 20 - 48 KiB: with one stage in flight a CU has ~40 KiB outstanding against a loaded HBM latency
+// of ~2 us - Little's law caps the chip at ~2.5 TB/s, which is what round 3 measured for them (2.0 - 2.5 TB/s of algorithmic
+// bytes at 0.25 - 0.65 MFMA-busy) while they ask for 3.6 - 6 TB/s.  Their stages are small, so the ring holds one or two more.
+template <int CB, int WM, int WK>
+constexpr int gemm_ring() {
+    constexpr size_t stage = (size_t)kGemmStagePts * (128 * WM + 32 * CB * WK) * sizeof(float);
+    return stage >= 64 * 1024 ? 2 : (stage > 20 * 1024 ? 3 : 4);
+}
 template <int CB, int WM, int WK>
 constexpr size_t gemm_lds_bytes() {
     constexpr int TILES = WM * WK, KS = 4 / TILES, TM = 128 * WM, TK = 32 * CB * WK;
-    constexpr size_t stage = (size_t)2 * kGemmStagePts * (TM + TK) * sizeof(float);
+    constexpr size_t stage = (size_t)gemm_ring<CB, WM, WK>() * kGemmStagePts * (TM + TK) * sizeof(float);
     constexpr size_t merge = (size_t)(KS - 1) * TILES * gemm_merge_wave_floats(CB) * sizeof(float);
     return stage > merge ? stage : merge;
 }
@@ -744,15 +754,26 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
             for (int r = 0; r < 16; ++r) acc[c][d][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
+    // Ring of NB stage buffers: stages st+1 .. st+NB-2 are in flight while stage st is consumed, and stage st+NB-1 is
+    // issued during it (into the buffer stage st-1 just left).  Every wave issues exactly NPW pieces per stage, ALWAYS -
+    // stages past the slab's end read zeros through the buffer bounds and are never consumed - so "stage st has landed" is
+    // `s_waitcnt vmcnt((NB - 2) * NPW)`: the wave's vector-memory operations complete in order and nothing else is issued
+    // in the loop.
+    constexpr int NB = gemm_ring<CB, WM, WK>();
+    static_assert((PA + PB) % 4 == 0, "every wave must issue the same number of pieces per stage (the vmcnt arithmetic)");
+    static_assert((NB - 2) * NPW < 64, "vmcnt is a 6-bit counter");
 #pragma unroll
-    for (int k = 0; k < NPW; ++k) issue(0, 0, k);
+    for (int sp = 0; sp < NB - 1; ++sp)
+#pragma unroll
+        for (int k = 0; k < NPW; ++k) issue(sp, sp, k);
+    int b = 0;
     for (int st = 0; st < n_stages; ++st) {
-        const int b = st & 1;
-        __syncthreads();                                             // stage st has landed (vmcnt(0) + barrier)
+        // stage st has landed in every wave's view: own pieces by the count, the others' by the barrier
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NB - 2) * NPW) : "memory");
+        const int bn = b == 0 ? NB - 1 : b - 1;                      // the buffer stage st - 1 used = (st + NB - 1) % NB
         // this wave's first point pair of the stage; step sidx reads rows 2 KS sidx further on (an immediate offset)
         const float* As = smem + b * STAGE + 128 * wm + 4 * i + (2 * ks + h) * TM;
         const float* Bs = smem + b * STAGE + T * TM + 32 * CB * wk + CB * i + (2 * ks + h) * TK;
-        const bool more = st + 1 < n_stages;
         // Operands one step ahead: the reads of step s + 1 are issued at the top of step s and pinned there, so their LDS
         // latency runs under the 4 CB MFMAs of step s.  (Left to the scheduler, the A operand of a step was read three MFMAs
         // before the step began with an s_waitcnt lgkmcnt(0) right behind it - the matrix pipe drained at every step: the
@@ -778,14 +799,16 @@ __global__ __launch_bounds__(256, 1) void dw_gemm_kernel(GemmBatch jobs, int64_t
                 constexpr int slot = sidx * PPS + c;
                 if constexpr (sidx < STEPS / 2 && c < PPS && slot < NPW) {
                     __builtin_amdgcn_sched_barrier(0);
-                    if (more) issue(st + 1, b ^ 1, slot);
+                    issue(st + NB - 1, bn, slot);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             });
             av = av_n;
             bv = bv_n;
         });
+        b = b + 1 == NB ? 0 : b + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the zero stages issued past the slab's end
     // The k-split waves of a workgroup (KS = 2 or 4 for the narrow tiles) hold partial sums of the SAME tile: they are
     // added here, through the stage buffers, in k order - one record per slab instead of KS (the narrow GEMMs of a
     // NeRF step wrote and re-read 2-4x the partial bytes of the wide ones for a fraction of their work).
