@@ -58,8 +58,12 @@ int mi_field_param_shape(int kind, int index, int64_t* rows, int64_t* cols);
  * HOST array of n_params device pointers in state-dict order) into the packed stream the
  * fused MLP kernel consumes.  Replaces nothing in the reference: it is the hand-off from
  * nn.Module parameters (nerf/nerf.py:59-73, pi_GAN/modules.py:76-94) to the kernel and is
- * called whenever the optimiser has changed the weights. */
-int mi_field_pack(int kind, const float* const* params, int n_params, float* packed, void* stream);
+ * called whenever the optimiser has changed the weights.
+ * w_0: the frequency of the kind's sin layers, sin(w_0 (gamma (W x + b) + beta)) - FilmSiren's constructor argument
+ * (pi_GAN/modules.py:11,22-25,73), any finite w_0 > 0, for the two FiLM kinds; every other kind has no such parameter
+ * (Siren hard-codes 30, nerf/nerf.py:112) and takes 30 only.  It travels in the stream (a trailer piece the kernels read as a
+ * wave-uniform scalar), so every entry point that consumes the stream evaluates the field it was packed for. */
+int mi_field_pack(int kind, const float* const* params, int n_params, float w_0, float* packed, void* stream);
 
 /* ---- fused field MLP forward ---------------------------------------------------- */
 
@@ -168,7 +172,7 @@ int mi_composite_bwd(int64_t n, int n_samples, const float* raw, const float* z,
 
 /* Transposed weight stream for the backward chain (second packed buffer, refreshed with the weights). */
 int64_t mi_field_packed_bwd_floats(int kind);
-int mi_field_pack_bwd(int kind, const float* const* params, int n_params, float* packed_bwd, void* stream);
+int mi_field_pack_bwd(int kind, const float* const* params, int n_params, float w_0, float* packed_bwd, void* stream);
 
 /* Per-point sizes (floats) of the training buffers, or -1 if the kind has no backward yet:
  * acts = layer inputs saved by the training forward; grads = per-layer dA written by the backward chain.

@@ -93,7 +93,19 @@ int mi_field_param_shape(int kind, int index, int64_t* rows, int64_t* cols) {
     return MI_OK;
 }
 
-int mi_field_pack(int kind, const float* const* params, int n_params, float* packed, void* stream) {
+// w_0 of the kind's sin layers: any finite w_0 > 0 for the FiLM kinds (FilmSiren's constructor argument, pi_GAN/modules.py:11,73);
+// every other kind has no such parameter (Siren hard-codes 30, nerf/nerf.py:112; the ReLU kinds have no sin) and takes 30 only.
+static int check_w0(int kind, float w_0, const char* fn) {
+    if (is_film(kind)) {
+        if (!(w_0 > 0.f) || !(w_0 < 1e30f)) { set_error("%s: w_0 = %g (FiLM kinds need a finite w_0 > 0)", fn, (double)w_0); return MI_EINVAL; }
+    } else if (w_0 != 30.f) {
+        set_error("%s: w_0 = %g, but only the FiLM kinds have a w_0 (pass 30 for kind %d)", fn, (double)w_0, kind);
+        return MI_EINVAL;
+    }
+    return MI_OK;
+}
+
+int mi_field_pack(int kind, const float* const* params, int n_params, float w_0, float* packed, void* stream) {
     if (bad_kind(kind)) return MI_EINVAL;
     if (!params || !packed) { set_error("null pointer argument"); return MI_EINVAL; }
     if (n_params != 2 * kNumLayers[kind]) {
@@ -102,7 +114,8 @@ int mi_field_pack(int kind, const float* const* params, int n_params, float* pac
     }
     for (int i = 0; i < n_params; ++i)
         if (!params[i]) { set_error("parameter %d is null", i); return MI_EINVAL; }
-    return launch_pack(kind, params, n_params, packed, (hipStream_t)stream);
+    if (int rc = check_w0(kind, w_0, "mi_field_pack")) return rc;
+    return launch_pack(kind, params, n_params, w_0, packed, (hipStream_t)stream);
 }
 
 int mi_field_eval_points(int kind, const float* packed, const float* film, const float* x, int64_t n_groups,
@@ -288,10 +301,11 @@ int mi_composite_bwd(int64_t n, int n_samples, const float* raw, const float* z,
 
 int64_t mi_field_packed_bwd_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : packed_floats(*host_table_bwd(kind)); }
 
-int mi_field_pack_bwd(int kind, const float* const* params, int n_params, float* packed_bwd, void* stream) {
+int mi_field_pack_bwd(int kind, const float* const* params, int n_params, float w_0, float* packed_bwd, void* stream) {
     if (bad_kind(kind)) return MI_EINVAL;
     if (!params || !packed_bwd || n_params != 2 * kNumLayers[kind]) { set_error("mi_field_pack_bwd: bad arguments"); return MI_EINVAL; }
-    return launch_pack_bwd(kind, params, n_params, packed_bwd, (hipStream_t)stream);
+    if (int rc = check_w0(kind, w_0, "mi_field_pack_bwd")) return rc;
+    return launch_pack_bwd(kind, params, n_params, w_0, packed_bwd, (hipStream_t)stream);
 }
 
 int64_t mi_field_train_acts_floats(int kind) { return bad_kind(kind) ? MI_EINVAL : train_acts_floats(kind); }

@@ -244,9 +244,14 @@ constexpr RegionLayout film_acts() {
 }
 constexpr RegionLayout film_grads() { return {10, {256, 256, 256, 256, 256, 256, 256, 256, 256, 4}}; }
 
-constexpr int packed_floats(const PackTable& t) {
+// The stream ends with a trailer piece of hyper-parameters the kernels read as wave-uniform scalars: [0] = w_0, the sin layers'
+// frequency (FilmSiren's constructor argument, pi_GAN/modules.py:11,73; 30 for every other kind), [1] = fl(w_0^2) for the
+// backward's rebuilt derivative.  Written by the pack kernels, left alone by the fused Adam's scatter refresh.
+constexpr int kTrailer = 256;
+constexpr int packed_body_floats(const PackTable& t) {
     const PackItem& last = t.item[t.n_items - 1];
     return t.dst_off[t.n_items - 1] + (last.type == ITEM_CHUNK ? last.mb * 1024 : kPiece);
 }
+constexpr int packed_floats(const PackTable& t) { return packed_body_floats(t) + kTrailer; }
 
 }  // namespace mi

@@ -61,10 +61,14 @@ __device__ __forceinline__ const PackTable& dev_table(int kind) {
 }
 
 // grid: (32, n_items); block 256.  One block row per item.
-__global__ void pack_kernel(int kind, ParamPtrs pp, float* __restrict__ dst) {
+__global__ void pack_kernel(int kind, ParamPtrs pp, float* __restrict__ dst, float w0) {
     const PackTable& t = dev_table(kind);
     const int it = blockIdx.y;
     if (it >= t.n_items) return;
+    if (it == 0 && blockIdx.x == 0) {                        // the trailer piece: hyper-parameters (field_layout.h:kTrailer)
+        float* tr = dst + packed_body_floats(t);
+        tr[threadIdx.x] = threadIdx.x == 0 ? w0 : (threadIdx.x == 1 ? w0 * w0 : 0.f);
+    }
     const PackItem item = t.item[it];
     float* out = dst + t.dst_off[it];
     const float* src = pp.p[item.param];
@@ -298,6 +302,9 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx(smem, a, group);
+    // FilmSiren's w_0 (pi_GAN/modules.py:11,73): the first float of the stream's trailer, a uniform (scalar) load
+    constexpr int kBody = USE_DIR ? packed_body_floats(h_tab_film) : packed_body_floats(h_tab_film_nodir);
+    c.w0 = a.packed[kBody];
     issue_first_stage<4, 0, true>(c, 0, 0, 0);   // input_layer: bias + 3 columns, FiLM row 0
 
     const PointIn pt = load_point(a.mode, a.a, a.z, group, a.points_per_group, a.rays_per_group, a.n_samples,
@@ -314,9 +321,9 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
     const auto film_act = [&](int l, int slot_) {
         if constexpr (SAVE)
             activate_train<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0, a.save + (int64_t)(8 + 256 * l) * SP, 256,
-                                        pt.p, pt.valid);
+                                        pt.p, pt.valid, c.w0);
         else
-            activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0);
+            activate<8, ACT_FILM>(acc, X, film_row(slot_), c.h, smem + kLdsAux0, c.w0);
     };
     if constexpr (SAVE) {
         if (pt.valid && c.h == 0) {
@@ -355,11 +362,11 @@ __global__ __launch_bounds__(256, 1) void film_fwd_kernel(MlpArgs a) {
 }
 
 // ---- host side ---------------------------------------------------------------------------
-int launch_pack(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream) {
+int launch_pack(int kind, const float* const* params, int n_params, float w0, float* packed, hipStream_t stream) {
     const PackTable* t = host_table(kind);
     ParamPtrs pp{};
     for (int i = 0; i < n_params && i < 24; ++i) pp.p[i] = params[i];
-    hipLaunchKernelGGL(pack_kernel, dim3(32, t->n_items), dim3(256), 0, stream, kind, pp, packed);
+    hipLaunchKernelGGL(pack_kernel, dim3(32, t->n_items), dim3(256), 0, stream, kind, pp, packed, w0);
     return check_launch("pack_kernel");
 }
 

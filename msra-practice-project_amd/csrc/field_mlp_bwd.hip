@@ -58,10 +58,14 @@ __device__ __forceinline__ const PackTable& dev_table_bwd(int kind) {
     }
 }
 
-__global__ void pack_bwd_kernel(int kind, ParamPtrsB pp, float* __restrict__ dst) {
+__global__ void pack_bwd_kernel(int kind, ParamPtrsB pp, float* __restrict__ dst, float w0) {
     const PackTable& t = dev_table_bwd(kind);
     const int it = blockIdx.y;
     if (it >= t.n_items) return;
+    if (it == 0 && blockIdx.x == 0) {                        // the trailer piece: hyper-parameters (field_layout.h:kTrailer)
+        float* tr = dst + packed_body_floats(t);
+        tr[threadIdx.x] = threadIdx.x == 0 ? w0 : (threadIdx.x == 1 ? w0 * w0 : 0.f);
+    }
     const PackItem item = t.item[it];
     float* out = dst + t.dst_off[it];
     const float* src = pp.p[item.param];
@@ -451,12 +455,12 @@ __global__ __launch_bounds__(256, 1) void siren_bwd_kernel(BwdArgs a) {
 // `cv`: the point's saved X_8 row, loaded by the caller at the top of the kernel (its latency then overlaps the first
 // weight stage's DMA and the head gradients instead of following them).
 template <int MB>
-__device__ __forceinline__ void film_bwd_first(const f32x16 (&dX)[8], f32x16 (&X)[8], const f32x4 (&cv)[32]) {
+__device__ __forceinline__ void film_bwd_first(const f32x16 (&dX)[8], f32x16 (&X)[8], const f32x4 (&cv)[32], float w0sq) {
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 c = dsin30_from_saved_x4(cv[m * 4 + rg]);
+            const f32x4 c = dsin_w_from_saved_x4(cv[m * 4 + rg], w0sq);
             const f32x4 o = c * f32x4{dX[m][4 * rg + 0], dX[m][4 * rg + 1], dX[m][4 * rg + 2], dX[m][4 * rg + 3]};
             X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
         }
@@ -509,7 +513,7 @@ __device__ __forceinline__ void film_chain_layer(Ctx& c, int piece, float s, f32
             // (K block 7 offers slots 0..15: the last two quarters, loaded in K block 6, are decoded in its slots 0 and 4)
             constexpr int j = (kb - 1) * 6 + slot / 4;
             if constexpr (kb >= 2 && j - 6 >= 0 && j - 6 < 32) {
-                ring[j - 6] = dsin30_from_saved_x4(ring[j - 6]);
+                ring[j - 6] = dsin_w_from_saved_x4(ring[j - 6], c.w0sq);
             }
             if constexpr (kb >= 1 && kb < 7 && j < 32) ring[j] = srow[(j / 4) * 8 + (j % 4) * 2];
         } else if constexpr (kb < 7 && slot < 16) {
@@ -540,6 +544,10 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
     const int64_t group = blockIdx.x / a.tiles_per_group;
     const int64_t tile = blockIdx.x % a.tiles_per_group;
     Ctx c = make_ctx_raw(smem, a.packed, a.film + group * (kFilmLayers * kFilmRow));
+    // fl(w_0^2) of the module's w_0 (pi_GAN/modules.py:11,73) from the backward stream's trailer: the rebuilt derivative
+    // factor is +-sqrt(w_0^2 (1 - X^2)); a uniform (scalar) load
+    constexpr int kBody = USE_DIR ? packed_body_floats(h_tabb_film) : packed_body_floats(h_tabb_film_nodir);
+    c.w0sq = a.packed[kBody + 1];
     const int64_t P = a.points;
     // rgb head rows x3, sigma row; K blocks 0-1 of hidden_layer_rgb^T; FiLM row 8 -> film slot 0 (row r lives in slot (8 - r) & 1)
     issue_first_stage<4, 32, true>(c, 0, 0, 8);
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void film_bwd_kernel(BwdArgs a) {
             }
     }
     MI_STAMP(a, 0);
-    film_bwd_first<8>(acc, X, ring);                                                             // hidden_layer_rgb: X = dU_8
+    film_bwd_first<8>(acc, X, ring, c.w0sq);                                                             // hidden_layer_rgb: X = dU_8
     MI_STAMP(a, 1);
     // Chain layer j multiplies by FiLM row j + 1 (slot (7 - j) & 1) and DMAs row j - what layer j - 1 multiplies by -
     // into the other slot.  j = 7 starts from the sigma head's row (aux slot 0, piece 3).
@@ -983,11 +991,11 @@ __global__ __launch_bounds__(256) void reduce_jobs_kernel(ReduceBatch rb) {
 }
 
 // ---- host orchestration ---------------------------------------------------------------------
-int launch_pack_bwd(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream) {
+int launch_pack_bwd(int kind, const float* const* params, int n_params, float w0, float* packed, hipStream_t stream) {
     const PackTable* t = host_table_bwd(kind);
     ParamPtrsB pp{};
     for (int i = 0; i < n_params && i < 24; ++i) pp.p[i] = params[i];
-    hipLaunchKernelGGL(pack_bwd_kernel, dim3(32, t->n_items), dim3(256), 0, stream, kind, pp, packed);
+    hipLaunchKernelGGL(pack_bwd_kernel, dim3(32, t->n_items), dim3(256), 0, stream, kind, pp, packed, w0);
     return check_launch("pack_bwd_kernel");
 }
 

@@ -44,6 +44,7 @@ struct Ctx {
     int buf;                        // stage buffer (0/1) holding the next stage to consume
     int voff;                       // per-lane byte offset inside a round of 4 pieces: wave * 1024 + lane * 16
     int lane, wave, h;
+    float w0, w0sq;                 // FiLM kinds: the layers' frequency w_0 and fl(w_0^2) from the packed stream's trailer (uniform)
 #ifdef MI_PROFILE_STAMPS
     unsigned long long* rowst;    // diagnostic build: next per-row stamp slot of this block (null = off)
 #endif
@@ -264,7 +265,7 @@ __device__ __forceinline__ void init_acc(const float* aux, int h, int k3_piece, 
 // Activation epilogue: X = act(acc + bias).  FiLM reads gamma|beta of this layer from the film slot.
 template <int MB, int ACT>
 __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
-                                         const float* aux) {
+                                         const float* aux, float w0 = 30.f) {
     const lds4_t pb = lds_base(aux + h * 16);
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);   // gamma at f, beta at 256 + f
@@ -284,7 +285,7 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
                 float o;
                 if constexpr (ACT == ACT_RELU) o = fmaxf(v, 0.f);
                 else if constexpr (ACT == ACT_SIN30) o = hw_sin30(v);
-                else if constexpr (ACT == ACT_FILM) o = hw_sin30(__fadd_rn(__fmul_rn(g[q], v), b[q]));
+                else if constexpr (ACT == ACT_FILM) o = hw_sin_w(__fadd_rn(__fmul_rn(g[q], v), b[q]), w0);
                 else o = v;
                 X[m][4 * rg + q] = o;
             }
@@ -297,7 +298,7 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[8], f32x16 (&X)[8],
 template <int MB, int ACT>
 __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&X)[8], const float* film_row, int h,
                                                const float* aux, float* __restrict__ x_rows, int64_t ld, int64_t p,
-                                               bool valid) {
+                                               bool valid, float w0 = 30.f) {
     static_assert(ACT == ACT_SIN30 || ACT == ACT_FILM, "sin activations only");
     const lds4_t pb = lds_base(aux + h * 16);
     lds4_t pf = nullptr;
@@ -318,7 +319,7 @@ __device__ __forceinline__ void activate_train(const f32x16 (&acc)[8], f32x16 (&
                 const float v = __fadd_rn(acc[m][4 * rg + q], bias[q]);
                 float u = v;
                 if constexpr (ACT == ACT_FILM) u = __fadd_rn(__fmul_rn(g[q], v), b[q]);
-                const SinSaved sc = hw_sin30_saved(u);
+                const SinSaved sc = hw_sin_w_saved(u, w0);
                 X[m][4 * rg + q] = sc.s;
                 xo[q] = sc.saved;
             }
@@ -446,12 +447,15 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
         else if constexpr (ACT == ACT_LINEAR) { o = v; xo = o; }
         else {
             if constexpr (ACT == ACT_FILM) v = film_affine(g_q[idx & 1], v, bb_q[idx & 1]);
+            // FiLM layers: w_0 is the module's (pi_GAN/modules.py:11,73), a wave-uniform scalar; Siren's is the literal 30
+            float w0 = 30.f;
+            if constexpr (ACT == ACT_FILM) w0 = c.w0;
             if constexpr (SAVE) {
-                const SinSaved4 sc = hw_sin30_saved_x4(v);
+                const SinSaved4 sc = hw_sin_w_saved_x4(v, w0);
                 o = sc.s;
                 xo = sc.saved;
             } else {
-                o = hw_sin30_x4(v);
+                o = hw_sin_w_x4(v, w0);
                 xo = o;
             }
         }
@@ -592,6 +596,8 @@ __device__ __forceinline__ Ctx make_ctx_raw(float* smem, const float* packed, co
     c.soff = 0;
     c.buf = 0;
     c.voff = c.wave * 1024 + c.lane * 16;
+    c.w0 = 30.f;
+    c.w0sq = 900.f;
 #ifdef MI_PROFILE_STAMPS
     c.rowst = nullptr;
 #endif

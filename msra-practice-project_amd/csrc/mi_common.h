@@ -71,9 +71,9 @@ struct MlpArgs {
 #endif
 
 // host launchers (field_mlp.hip, render_stages.hip)
-int launch_pack(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream);
+int launch_pack(int kind, const float* const* params, int n_params, float w0, float* packed, hipStream_t stream);
 int launch_mlp(int kind, const MlpArgs& a, int64_t n_groups, hipStream_t stream);
-int launch_pack_bwd(int kind, const float* const* params, int n_params, float* packed, hipStream_t stream);
+int launch_pack_bwd(int kind, const float* const* params, int n_params, float w0, float* packed, hipStream_t stream);
 int64_t train_acts_floats(int kind);
 int64_t train_grads_floats(int kind);
 int64_t bwd_partial_floats(int64_t P);

@@ -62,19 +62,24 @@ __device__ __forceinline__ float hw_turns(float t) {
 #ifndef MI_SIN_VARIANT
 #define MI_SIN_VARIANT 0
 #endif
-__device__ __forceinline__ float hw_turns30(float u) {
+// w0: the layer's frequency - the literal 30 of nerf/nerf.py:112 (Siren hard-codes it) or FilmSiren's constructor argument
+// (pi_GAN/modules.py:11,73), which the FiLM kernels read from the packed stream's trailer (field_layout.h:kTrailer).
+// With the literal the code is what it was: t = fl(w0 u) is formed first, like torch.sin(w_0 * x).
+__device__ __forceinline__ float hw_turns_w(float u, float w0) {
 #pragma clang fp contract(off)
-    return hw_turns_fast(30.f * u);
+    return hw_turns_fast(w0 * u);
 }
+__device__ __forceinline__ float hw_turns30(float u) { return hw_turns_w(u, 30.f); }
 #if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1     // diagnostic builds only (tools/diag_build.sh): no activation work at all
-__device__ __forceinline__ float hw_sin30(float u) { return u; }
+__device__ __forceinline__ float hw_sin_w(float u, float w0) { return u; }
 #elif defined(MI_DIAG_SIN) && MI_DIAG_SIN == 2   // ... the transcendental alone, no range reduction
-__device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(u); }
+__device__ __forceinline__ float hw_sin_w(float u, float w0) { return __builtin_amdgcn_sinf(u); }
 #elif defined(MI_DIAG_SIN) && MI_DIAG_SIN == 3   // ... the reduction alone, no transcendental
-__device__ __forceinline__ float hw_sin30(float u) { return hw_turns30(u); }
+__device__ __forceinline__ float hw_sin_w(float u, float w0) { return hw_turns_w(u, w0); }
 #else
-__device__ __forceinline__ float hw_sin30(float u) { return __builtin_amdgcn_sinf(hw_turns30(u)); }
+__device__ __forceinline__ float hw_sin_w(float u, float w0) { return __builtin_amdgcn_sinf(hw_turns_w(u, w0)); }
 #endif
+__device__ __forceinline__ float hw_sin30(float u) { return hw_sin_w(u, 30.f); }
 
 // Two elements at a time on the packed fp32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32, full rate on
 // gfx90a+): the wave runs ONE instruction stream per SIMD, and measured (tools/probes/mfma_valu_overlap.hip) every
@@ -116,25 +121,28 @@ __device__ __forceinline__ float cos_sign_into(float sn, float r) {
     return __uint_as_float((__float_as_uint(sn) & ~1u) | (__float_as_uint(y) & 1u));
 }
 struct SinSaved { float s, saved; };
-__device__ __forceinline__ SinSaved hw_sin30_saved(float u) {
-    const float r = hw_turns30(u);
+__device__ __forceinline__ SinSaved hw_sin_w_saved(float u, float w0) {
+    const float r = hw_turns_w(u, w0);
     const float sn = __builtin_amdgcn_sinf(r);
     return {sn, cos_sign_into(sn, r)};
 }
-__device__ __forceinline__ float dsin30_from_saved(float xs) {
-    // 900 (1 - X^2); |X| <= 1 makes it non-negative, and the |.| (a free source modifier of v_sqrt) keeps a
+__device__ __forceinline__ SinSaved hw_sin30_saved(float u) { return hw_sin_w_saved(u, 30.f); }
+// w0sq = fl(w0 w0) (900 for the literal): the derivative factor is +-sqrt(w0^2 (1 - X^2)) = w0 |cos(w0 u)|, w0 > 0
+__device__ __forceinline__ float dsin_w_from_saved(float xs, float w0sq) {
+    // w0^2 (1 - X^2); |X| <= 1 makes it non-negative, and the |.| (a free source modifier of v_sqrt) keeps a
     // transcendental-unit result one ulp above 1 from turning into a NaN
     // (the root is non-negative, so the sign goes in with an OR: one v_lshl_or_b32 instead of a shift and an xor)
-    const float y = fmaf(xs * -900.f, xs, 900.f);
+    const float y = fmaf(xs * -w0sq, xs, w0sq);
     return __uint_as_float((__float_as_uint(xs) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y))));
 }
+__device__ __forceinline__ float dsin30_from_saved(float xs) { return dsin_w_from_saved(xs, 900.f); }
 // Four saved values (one row quarter) at a time: the squares and the fma as two packed instructions each - 3 instead of 4
 // VALU instructions per element, same roundings as the scalar form (fl(fl(x * -900) * x + 900)).
 typedef float f32x4d __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4d dsin30_from_saved_x4(f32x4d xs) {
+__device__ __forceinline__ f32x4d dsin_w_from_saved_x4(f32x4d xs, float w0sq) {
 #pragma clang fp contract(off)
-    const f32x4d k = {900.f, 900.f, 900.f, 900.f};
-    const f32x4d y = __builtin_elementwise_fma(xs * -900.f, xs, k);
+    const f32x4d k = {w0sq, w0sq, w0sq, w0sq};
+    const f32x4d y = __builtin_elementwise_fma(xs * -w0sq, xs, k);
     f32x4d o;
     o.x = __uint_as_float((__float_as_uint(xs.x) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.x))));
     o.y = __uint_as_float((__float_as_uint(xs.y) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.y))));
@@ -142,6 +150,7 @@ __device__ __forceinline__ f32x4d dsin30_from_saved_x4(f32x4d xs) {
     o.w = __uint_as_float((__float_as_uint(xs.w) << 31) | __float_as_uint(__builtin_amdgcn_sqrtf(fabsf(y.w))));
     return o;
 }
+__device__ __forceinline__ f32x4d dsin30_from_saved_x4(f32x4d xs) { return dsin_w_from_saved_x4(xs, 900.f); }
 struct SinSaved2 { f32x2 s, saved; };
 __device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {
     const f32x2 r = hw_turns30_x2(u);
@@ -159,25 +168,25 @@ __device__ __forceinline__ SinSaved2 hw_sin30_saved_x2(f32x2 u) {
 // independent packed instructions back to back and the wait states disappear: 4.5 instead of 6.5-7 issue slots per
 // element for the default reduction.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4m hw_turns30_x4(f32x4m u) {
+__device__ __forceinline__ f32x4m hw_turns_w_x4(f32x4m u, float w0) {
 #pragma clang fp contract(off)
     const float c_hi = 0.15915494309189535f;
 #if MI_SIN_VARIANT == 0
     const float c_lo = (float)(0.15915494309189533577 - (double)0.15915494309189535f);
-    const f32x4m t = u * 30.f, hi = t * c_hi;
+    const f32x4m t = u * w0, hi = t * c_hi;
     const f32x4m n = {rintf(hi.x), rintf(hi.y), rintf(hi.z), rintf(hi.w)};
     const f32x4m k_hi = {c_hi, c_hi, c_hi, c_hi}, k_lo = {c_lo, c_lo, c_lo, c_lo};
     return __builtin_elementwise_fma(t, k_lo, __builtin_elementwise_fma(t, k_hi, -n));
 #elif MI_SIN_VARIANT == 1
-    const f32x4m t = u * 30.f, hi = t * c_hi;
+    const f32x4m t = u * w0, hi = t * c_hi;
     const f32x4m n = {rintf(hi.x), rintf(hi.y), rintf(hi.z), rintf(hi.w)};
     const f32x4m k_hi = {c_hi, c_hi, c_hi, c_hi};
     return __builtin_elementwise_fma(t, k_hi, -n);
 #elif MI_SIN_VARIANT == 2
-    const f32x4m hi = (u * 30.f) * c_hi;
+    const f32x4m hi = (u * w0) * c_hi;
     return f32x4m{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y), __builtin_amdgcn_fractf(hi.z), __builtin_amdgcn_fractf(hi.w)};
 #else
-    const f32x4m hi = u * 4.774648292756860f;
+    const f32x4m hi = u * (w0 * 0.15915494309189535f);
     return f32x4m{__builtin_amdgcn_fractf(hi.x), __builtin_amdgcn_fractf(hi.y), __builtin_amdgcn_fractf(hi.z), __builtin_amdgcn_fractf(hi.w)};
 #endif
 }
@@ -188,23 +197,26 @@ __device__ __forceinline__ f32x4m hw_sin4(f32x4m r) {
     return f32x4m{__builtin_amdgcn_sinf(r.x), __builtin_amdgcn_sinf(r.y), __builtin_amdgcn_sinf(r.z), __builtin_amdgcn_sinf(r.w)};
 #endif
 }
-__device__ __forceinline__ f32x4m hw_sin30_x4(f32x4m u) {
+__device__ __forceinline__ f32x4m hw_turns30_x4(f32x4m u) { return hw_turns_w_x4(u, 30.f); }
+__device__ __forceinline__ f32x4m hw_sin_w_x4(f32x4m u, float w0) {
 #if defined(MI_DIAG_SIN) && MI_DIAG_SIN == 1
     return u;
 #elif defined(MI_DIAG_SIN) && MI_DIAG_SIN == 2
     return hw_sin4(u);
 #else
-    return hw_sin4(hw_turns30_x4(u));
+    return hw_sin4(hw_turns_w_x4(u, w0));
 #endif
 }
+__device__ __forceinline__ f32x4m hw_sin30_x4(f32x4m u) { return hw_sin_w_x4(u, 30.f); }
 struct SinSaved4 { f32x4m s, saved; };
-__device__ __forceinline__ SinSaved4 hw_sin30_saved_x4(f32x4m u) {
-    const f32x4m r = hw_turns30_x4(u);
+__device__ __forceinline__ SinSaved4 hw_sin_w_saved_x4(f32x4m u, float w0) {
+    const f32x4m r = hw_turns_w_x4(u, w0);
     const f32x4m sn = hw_sin4(r);
     SinSaved4 o;
     o.s = sn;
     o.saved = f32x4m{cos_sign_into(sn.x, r.x), cos_sign_into(sn.y, r.y), cos_sign_into(sn.z, r.z), cos_sign_into(sn.w, r.w)};
     return o;
 }
+__device__ __forceinline__ SinSaved4 hw_sin30_saved_x4(f32x4m u) { return hw_sin_w_saved_x4(u, 30.f); }
 
 }  // namespace mi

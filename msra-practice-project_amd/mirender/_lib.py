@@ -31,7 +31,7 @@ SIGNATURES = {
     "mi_field_packed_floats": (_i64, [_int]),
     "mi_field_macs": (_i64, [_int]),
     "mi_field_param_shape": (_int, [_int, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
-    "mi_field_pack": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),
+    "mi_field_pack": (_int, [_int, ctypes.POINTER(_vp), _int, _f32, _vp, _vp]),
     "mi_field_eval_points": (_int, [_int, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mi_field_eval_rays": (_int, [_int, _vp, _vp, _vp, _vp, _i64, _i64, _int, _vp, _vp]),
     "mi_gen_rays": (_int, [_int, _int, _f64, ctypes.POINTER(_f32), _i64, _i64, _vp, _int, _vp]),
@@ -57,7 +57,7 @@ SIGNATURES = {
                               _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mi_composite_bwd": (_int, [_i64, _int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_field_packed_bwd_floats": (_i64, [_int]),
-    "mi_field_pack_bwd": (_int, [_int, ctypes.POINTER(_vp), _int, _vp, _vp]),
+    "mi_field_pack_bwd": (_int, [_int, ctypes.POINTER(_vp), _int, _f32, _vp, _vp]),
     "mi_field_train_acts_floats": (_i64, [_int]),
     "mi_field_train_grads_floats": (_i64, [_int]),
     "mi_field_bwd_partial_floats": (_i64, [_i64]),

@@ -75,7 +75,9 @@ def detect_kind(named_params: dict) -> int | None:
     return None
 
 
-W_0 = 30.0     # the one frequency the sin kernels implement (nerf/nerf.py:112 hard-codes it; FilmSiren's default, modules.py:11)
+W_0 = 30.0     # Siren's hard-coded frequency (nerf/nerf.py:112) and FilmSiren's default (pi_GAN/modules.py:11).  The FiLM
+#                kernels take the module's own w_0 at run time (one value per network, as FilmSirenNeRF passes one to every
+#                layer, modules.py:73-94): it travels in the packed stream (mi_field_pack).
 
 
 def expected_activation(kind: int, key: str) -> str:
@@ -97,6 +99,20 @@ def _layer_module(model, key):
     for part in key.split("."):
         mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
     return mod
+
+
+def film_w0(model, kind: int) -> float:
+    """The w_0 the fused kernels run a recognised module with: its first FiLM layer's `w_0` attribute (the reference's
+    FilmSirenNeRF gives every layer the same one, pi_GAN/modules.py:73-94; hyper_mismatch refuses a module whose layers
+    disagree), our own modules' `w_0`, 30 for everything else."""
+    if not is_film(kind):
+        return W_0
+    if hasattr(model, "mi_w_0"):
+        return float(model.mi_w_0)
+    try:
+        return float(getattr(_layer_module(model, SPECS[kind][0][0]), "w_0", W_0))
+    except (AttributeError, IndexError, KeyError, TypeError):
+        return W_0
 
 
 def hyper_mismatch(model, kind: int) -> str | None:
@@ -123,8 +139,11 @@ def hyper_mismatch(model, kind: int) -> str | None:
         elif hasattr(mod, "activation_name"):
             have = mod.activation_name
         elif hasattr(mod, "w_0"):
-            if float(mod.w_0) != W_0:
-                return f"{key}: w_0 = {mod.w_0} (the fused kernels implement w_0 = {W_0:g} only)"
+            w = float(mod.w_0)
+            if not (w > 0.0 and math.isfinite(w)):
+                return f"{key}: w_0 = {mod.w_0} (the fused kernels need a finite w_0 > 0)"
+            if w != film_w0(model, kind):
+                return f"{key}: w_0 = {mod.w_0} differs from the first FiLM layer's (the fused kernels take one w_0 per network)"
             have = "film"
         elif type(mod).__name__ == "Siren":
             have = "sin"
@@ -144,9 +163,10 @@ def hyper_mismatch(model, kind: int) -> str | None:
 class PackedField:
     """Packed MFMA-ordered weights of one model, refreshed lazily from its live parameters."""
 
-    def __init__(self, kind: int, params: list):
+    def __init__(self, kind: int, params: list, w_0: float = W_0):
         self.kind = kind
         self.params = params                      # live tensors, state-dict order (w0,b0,w1,b1,...)
+        self.w_0 = float(w_0)                     # FiLM kinds: the module's w_0, packed into the streams' trailer
         self.device = None
         self._epoch = 0                           # bumped by writers that bypass the version counters (FusedAdam)
         self._follow_device()
@@ -169,7 +189,7 @@ class PackedField:
         In-place updates through torch ops (optimiser steps, load_state_dict, `p.mul_()` under no_grad) bump the
         counter; writes through `.data` (the reference's `bias.data[:n] = 1`, pi_GAN/modules.py:57-58) do NOT -
         call invalidate() after such a write."""
-        return (self._epoch,) + tuple((p.data_ptr(), p._version) for p in self.params)
+        return (self._epoch, self.w_0) + tuple((p.data_ptr(), p._version) for p in self.params)
 
     def note_fused_update(self):
         """A kernel rewrote the parameters AND every existing packed stream consistently (mirender.train.FusedAdam):
@@ -207,7 +227,7 @@ class PackedField:
         srcs = self._sources()
         arr = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
         with torch.cuda.device(self.device):
-            _lib.check(lib.mi_field_pack_bwd(self.kind, arr, len(srcs), _lib.ptr(self.packed_bwd),
+            _lib.check(lib.mi_field_pack_bwd(self.kind, arr, len(srcs), self.w_0, _lib.ptr(self.packed_bwd),
                                              _lib.stream_ptr(self.device)), "mi_field_pack_bwd")
         self._keep_bwd = srcs
         self._versions_bwd = vers
@@ -222,7 +242,7 @@ class PackedField:
         srcs = self._sources()
         arr = (ctypes.c_void_p * len(srcs))(*[t.data_ptr() for t in srcs])
         with torch.cuda.device(self.device):
-            _lib.check(lib.mi_field_pack(self.kind, arr, len(srcs), _lib.ptr(self.packed),
+            _lib.check(lib.mi_field_pack(self.kind, arr, len(srcs), self.w_0, _lib.ptr(self.packed),
                                          _lib.stream_ptr(self.device)), "mi_field_pack")
         self._keep = srcs
         self._versions = vers
@@ -281,7 +301,7 @@ def as_packed_field(model) -> PackedField | None:
         params = []
         for key, _ in SPECS[kind]:
             params += [named[key + ".weight"], named[key + ".bias"]]
-        pf = PackedField(kind, params)
+        pf = PackedField(kind, params, film_w0(model, kind))
         _field_cache[model] = pf
     return pf or None
 
@@ -411,17 +431,27 @@ class SirenNeRF(_FusedField):
 
 
 class FilmSirenNeRF(_FusedField):
-    """pi_GAN/modules.py:70-118.  FiLM parameters are per-image state set by set_film_params
-    (modules.py:96-99) or passed to forward, as in the reference."""
+    """pi_GAN/modules.py:70-118, same constructor arguments (:73).  FiLM parameters are per-image state set by
+    set_film_params (modules.py:96-99) or passed to forward, as in the reference.  `c` and `w_0` shape the initialisation
+    (modules.py:27-31) and w_0 is the frequency the fused kernels run with; the fused kernels exist for the reference's own
+    topology (hidden_dim 256, 8 layers) - other sizes have no kernel here and raise."""
     KIND = FILM_SIREN_NERF
 
-    def __new__(cls, use_dir=True, **kw):
+    def __new__(cls, hidden_dim=256, hidden_layers=8, c=6, w_0=30, use_dir=True):
         if cls is FilmSirenNeRF and not use_dir:
             return super().__new__(FilmSirenNeRFNoDir)
         return super().__new__(cls)
 
-    def __init__(self, use_dir=True, **kw):
+    def __init__(self, hidden_dim=256, hidden_layers=8, c=6, w_0=30, use_dir=True):
+        if (hidden_dim, hidden_layers) != (256, 8):
+            raise _lib.MiRenderError(f"FilmSirenNeRF(hidden_dim={hidden_dim}, hidden_layers={hidden_layers}): the fused kernels "
+                                     "implement the reference's default topology (256, 8) only; build the reference's own "
+                                     "module for other sizes - render_rays drives it through the generic path")
+        if not (float(w_0) > 0.0 and math.isfinite(float(w_0))):
+            raise _lib.MiRenderError(f"FilmSirenNeRF(w_0={w_0}): need a finite w_0 > 0")
+        self.c, self.mi_w_0 = c, float(w_0)       # before super().__init__: reset_parameters reads them
         super().__init__()
+        self.w_0 = w_0
         self.use_dir = use_dir
         self.film_params = None
 
@@ -433,7 +463,7 @@ class FilmSirenNeRF(_FusedField):
                 torch.nn.init.uniform_(lay.weight, -b, b)
                 torch.nn.init.uniform_(lay.bias, -b, b)
             else:  # FilmSiren.reset_parameters pi_GAN/modules.py:27-31
-                wb = 1 / i if key == "input_layer" else math.sqrt(6 / i) / 30
+                wb = 1 / i if key == "input_layer" else math.sqrt(self.c / i) / self.mi_w_0
                 torch.nn.init.uniform_(lay.weight, -wb, wb)
                 torch.nn.init.uniform_(lay.bias, -math.sqrt(1 / i), math.sqrt(1 / i))
 
@@ -452,18 +482,20 @@ class FilmSirenNeRF(_FusedField):
 class FilmSirenNeRFNoDir(FilmSirenNeRF):
     KIND = FILM_SIREN_NERF_NODIR
 
-    def __init__(self, use_dir=False, **kw):
-        super().__init__(use_dir=False)
+    def __init__(self, hidden_dim=256, hidden_layers=8, c=6, w_0=30, use_dir=False):
+        super().__init__(hidden_dim, hidden_layers, c, w_0, use_dir=False)
 
 
-def field_from_state_dict(sd: dict, device="cuda") -> torch.nn.Module:
-    """Build the matching fused module for a reference state dict (checkpoint interop)."""
+def field_from_state_dict(sd: dict, device="cuda", w_0: float = W_0) -> torch.nn.Module:
+    """Build the matching fused module for a reference state dict (checkpoint interop).  `w_0`: FiLM kinds only - a state
+    dict does not carry FilmSiren's constructor argument (pi_GAN/modules.py:11,73), so a checkpoint of a w_0 != 30 network
+    needs it said."""
     kind = detect_kind(sd)
     if kind is None:
         raise _lib.MiRenderError("state dict does not match a known field layout")
     cls = {NERF: NeRF, SIREN_NERF: SirenNeRF, FILM_SIREN_NERF: FilmSirenNeRF,
            FILM_SIREN_NERF_NODIR: FilmSirenNeRFNoDir, TINY_NERF: TinyNeRF}[kind]
-    m = cls()
+    m = cls(w_0=w_0) if is_film(kind) else cls()
     m.load_state_dict({k: torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
                        for k, v in sd.items()})
     return m.to(device)

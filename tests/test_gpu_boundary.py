@@ -118,31 +118,34 @@ def test_two_devices_two_threads_one_process():
         assert np.array_equal(a.numpy(), b.numpy())
 
 
-def test_same_layout_other_w0_takes_the_generic_path_and_matches_the_oracle(monkeypatch):
-    """pi_GAN/modules.py:11,73: `FilmSirenNeRF(w_0=...)` is a constructor argument.  An object with the FiLM layout
-    but w_0 = 25 must NOT run the fused kernel (which hard-codes 30): it is driven through the generic path - its own
-    forward between the sampling / compositing kernels - and must match the oracle evaluated with w_0 = 25."""
+def test_w0_is_the_modules_own_whichever_path_renders_it(monkeypatch):
+    """pi_GAN/modules.py:11,73: `FilmSirenNeRF(w_0=...)` is a constructor argument.  An object with the FiLM layout whose
+    layers name their w_0 like the reference's runs the fused kernels WITH that w_0 (round 4: it travels in the packed
+    stream; round 3 refused anything but 30); one whose layers do not say (the same number under another attribute name) is
+    driven through the generic path - its own forward between the sampling / compositing kernels.  Either way the image
+    must match the oracle evaluated with that w_0."""
     from mirender import fields, render_core
     from oracle import fields as ofields, parity
 
     class FilmSiren(torch.nn.Module):                       # the reference layer's arithmetic (modules.py:22-25)
-        def __init__(self, i, o, w_0):
+        def __init__(self, i, o, w_0, named):
             super().__init__()
-            self.w_0 = w_0
+            setattr(self, "w_0" if named else "omega", w_0)
             self.weight = torch.nn.Parameter(torch.zeros(o, i))
             self.bias = torch.nn.Parameter(torch.zeros(o))
 
         def forward(self, x, gamma, beta):
-            return torch.sin(self.w_0 * (gamma * torch.nn.functional.linear(x, self.weight, self.bias) + beta))
+            w = self.w_0 if hasattr(self, "w_0") else self.omega
+            return torch.sin(w * (gamma * torch.nn.functional.linear(x, self.weight, self.bias) + beta))
 
     class LookAlike(torch.nn.Module):                       # modules.py:70-118
-        def __init__(self, w_0):
+        def __init__(self, w_0, named):
             super().__init__()
             self.film_params = None
-            self.input_layer = FilmSiren(3, 256, w_0)
-            self.hidden_layers = torch.nn.ModuleList([FilmSiren(256, 256, w_0) for _ in range(7)])
+            self.input_layer = FilmSiren(3, 256, w_0, named)
+            self.hidden_layers = torch.nn.ModuleList([FilmSiren(256, 256, w_0, named) for _ in range(7)])
             self.output_layer_sigma = torch.nn.Sequential(torch.nn.Linear(256, 1), torch.nn.ReLU())
-            self.hidden_layer_rgb = FilmSiren(259, 256, w_0)
+            self.hidden_layer_rgb = FilmSiren(259, 256, w_0, named)
             self.output_layer_rgb = torch.nn.Sequential(torch.nn.Linear(256, 3), torch.nn.Sigmoid())
 
         def forward(self, x):
@@ -159,13 +162,13 @@ def test_same_layout_other_w0_takes_the_generic_path_and_matches_the_oracle(monk
     film = synth.film_params(1, seed=6)[0]
     rays = torch.from_numpy(R.rays_from_camera(16, 16, 76.0, synth.pose_radians(1.0, 0.15, -0.1)))
     tr = synth.t_rand(256, 8, seed=2)
-    for w_0 in (25.0, 30.0):
-        m = LookAlike(w_0).to(dev())
+    for w_0, named in ((25.0, False), (25.0, True), (30.0, True), (17.0, True)):
+        m = LookAlike(w_0, named).to(dev())
         m.load_state_dict(sd)
         m.film_params = [torch.chunk(film[i].to(dev()), 2) for i in range(9)]
         assert fields.detect_kind(dict(m.named_parameters())) == fields.FILM_SIREN_NERF
         pf = fields.as_packed_field(m)
-        assert (pf is None) == (w_0 != 30.0)                # 30: the fused kernel; 25: not claimed
+        assert (pf is None) == (not named) and (pf is None or pf.w_0 == w_0)   # named: the fused kernels, with its w_0
         monkeypatch.setattr(ofields, "W0", w_0)
         fo = ofields.make_field("film_siren_nerf", sd, film)
         with torch.no_grad():
@@ -181,7 +184,8 @@ def test_same_layout_other_w0_takes_the_generic_path_and_matches_the_oracle(monk
         parity.record(case=case, stage="end-to-end fine", qty="rgb", err_vs_oracle32=float(d.max()), tol=1e-4,
                       frac_rays_over=frac, active="distribution", passed=frac <= 0.03)
         assert frac <= 0.03, (w_0, float(d.max()), frac)
-    # and the two really differ: had w_0 = 25 been routed to the fused kernel, the coarse image would be the w_0 = 30 one
+    # and the frequencies really differ: a kernel that ignored the module's w_0 (round 3's hard-coded 30) would have painted
+    # the w_0 = 30 image for the w_0 = 25 module
     monkeypatch.setattr(ofields, "W0", 30.0)
     fo30 = ofields.make_field("film_siren_nerf", sd, film)
     with torch.no_grad():

@@ -204,10 +204,11 @@ def _rebuild_from_attrs(kind_name, layers):
 
 
 def test_same_layout_other_arithmetic_is_not_claimed():
-    """a recognised layout is not enough - the kernels hard-code each layer's activation and w_0 = 30.
-    The reference's own classes (their layer objects' self-description dumped into ref_layer_attrs.json by importing
-    them) must pass; FilmSirenNeRF(w_0=25) (pi_GAN/modules.py:73), a Dense stack with another activation name
-    (nerf/nerf.py:15-16) and a bare nn.Linear stack must fall to the generic path (as_packed_field -> None)."""
+    """a recognised layout is not enough - the kernels hard-code each layer's activation.  The reference's
+    own classes (their layer objects' self-description dumped into ref_layer_attrs.json by importing them) must pass -
+    FilmSirenNeRF(w_0=25) (pi_GAN/modules.py:73) included since round 4: the FiLM kernels take the module's w_0 at run time -
+    while FiLM layers that disagree about w_0, a Dense stack with another activation name (nerf/nerf.py:15-16) and a bare
+    nn.Linear stack must fall to the generic path (as_packed_field -> None)."""
     import json
     import os
     from mirender import fields
@@ -217,11 +218,17 @@ def test_same_layout_other_arithmetic_is_not_claimed():
         kind, m = _rebuild_from_attrs(rec["kind"], rec["layers"])
         assert fields.detect_kind(dict(m.named_parameters())) == kind, name
         why = fields.hyper_mismatch(m, kind)
-        if "w_0=25" in name:
-            assert why is not None and "w_0" in why, (name, why)
-            assert fields.as_packed_field(m) is None           # generic path; no device needed to decide that
-        else:
-            assert why is None, (name, why)
+        assert why is None, (name, why)
+        assert fields.film_w0(m, kind) == (25.0 if "w_0=25" in name else 30.0), name
+    # one FiLM layer with another w_0 than the rest: one scalar per network is all the kernels take
+    layers = json.loads(json.dumps(ref["pi_GAN.FilmSirenNeRF(w_0=25)"]["layers"]))
+    layers["hidden_layers.3"]["w_0"] = 30
+    kind, m = _rebuild_from_attrs("film_siren_nerf", layers)
+    why = fields.hyper_mismatch(m, kind)
+    assert why is not None and "w_0" in why and fields.as_packed_field(m) is None    # generic path; no device needed to decide
+    layers["hidden_layers.3"]["w_0"] = -25
+    kind, m = _rebuild_from_attrs("film_siren_nerf", layers)
+    assert "w_0" in fields.hyper_mismatch(m, kind)
     # NeRF layout, one hidden Dense switched to tanh; SirenNeRF layout whose sin layers are Dense('relu')
     layers = json.loads(json.dumps(ref["nerf.NeRF"]["layers"]))
     layers["layers_pos.3"]["activation_name"] = "tanh"
@@ -240,6 +247,13 @@ def test_same_layout_other_arithmetic_is_not_claimed():
     # our own modules name their activations and are claimed
     for cls in (fields.NeRF, fields.TinyNeRF, fields.SirenNeRF, fields.FilmSirenNeRF, fields.FilmSirenNeRFNoDir):
         assert fields.hyper_mismatch(cls(), cls.KIND) is None, cls
+    # ... and keep the reference's constructor (pi_GAN/modules.py:73): w_0 / c shape the initialisation and w_0 the kernels
+    m = fields.FilmSirenNeRF(w_0=25, c=4)
+    assert fields.film_w0(m, m.KIND) == 25.0 and fields.hyper_mismatch(m, m.KIND) is None
+    assert float(m.hidden_layers[2].weight.abs().max()) <= np.sqrt(4 / 256) / 25 + 1e-7
+    assert isinstance(fields.FilmSirenNeRF(256, 8, 6, 30, False), fields.FilmSirenNeRFNoDir)
+    with pytest.raises(fields._lib.MiRenderError):
+        fields.FilmSirenNeRF(hidden_dim=128)
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="uses the absence of a GPU as the rank failure")

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = ctypes.CDLL(os.path.join(ROOT, "gpurun_tools", "libmirender_prof.so"))
 vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
 lib.mi_field_packed_floats.restype = i64
-lib.mi_field_pack.argtypes = [i32, ctypes.POINTER(vp), i32, vp, vp]
+lib.mi_field_pack.argtypes = [i32, ctypes.POINTER(vp), i32, ctypes.c_float, vp, vp]
 lib.mi_field_eval_points.argtypes = [i32, vp, vp, vp, i64, i64, vp, vp]
 lib.mi_debug_set_stamps.argtypes = [vp]
 dev = torch.device("cuda", 0)
@@ -27,7 +27,7 @@ for o, i in shapes:
     params += [torch.randn(o, i, device=dev) * (2.0 / (i + o)) ** 0.5, torch.zeros(o, device=dev)]
 packed = torch.empty(lib.mi_field_packed_floats(0), dtype=torch.float32, device=dev)
 arr = (vp * len(params))(*[p.data_ptr() for p in params])
-lib.mi_field_pack(0, arr, len(params), vp(packed.data_ptr()), None)
+lib.mi_field_pack(0, arr, len(params), 30.0, vp(packed.data_ptr()), None)
 M = 128 * 256 * 24                      # 24 tiles per CU
 x = torch.rand((M, 6), device=dev) * 2 - 1
 out = torch.empty((M, 4), device=dev)
