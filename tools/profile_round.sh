@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench line, rocprofv3 kernel stats and the PMC passes behind profiles/.
 # Usage: bash tools/profile_round.sh [c3|train|all]   (outputs under gpurun_out/; then, in the build container,
-#        python tools/summarise_pmc.py r03   copies the summaries into profiles/ under that round's name)
+#        python tools/summarise_pmc.py r04   copies the summaries into profiles/ under that round's name)
 # Counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa traces).  One gpurun call holds at
 # most 20 minutes: `c3` (the headline frame: bench line, kernel stats, four PMC passes) and `train` (C4 / C5 / nerf step:
 # bench line, kernel stats, three PMC passes each) fit one call each.
