@@ -184,9 +184,11 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         shrunk = os.environ.get("MI_BENCH_REHEARSAL") == "1" and world > 2
         if shrunk:                  # rehearsal with several ranks on ONE device: a full-size step per rank would not fit it
             res = 64
+        torch.manual_seed(0)                   # the SAME generator on every rank (data-parallel replicas) ...
         gen = pigan.Generator(256, res, near=0.5, far=1.5, fov=12, coarse_samples=nc, fine_samples=nf).to(dev)
         params = list(gen.parameters())
         opt = torch.optim.Adam(params, lr=5e-5, betas=(0.0, 0.9))
+        torch.manual_seed(1000 + rank)         # ... its own latents (its share of the global batch) on each
         z = torch.randn(b, 256, device=dev)
         rays_per_step = b * res * res
         # SURVEY.md 8d counts what the reference executes: coarse forward + 3 x the fine pass's Nc + Nf points (+ the D-step's
@@ -219,6 +221,7 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         params = list(coarse.parameters()) + list(fine.parameters())
         # train_nerf.py:98's Adam, fused with the repack of both MFMA weight streams of both models: one launch
         opt = train.FusedAdam([coarse, fine], lr=5e-4, betas=(0.9, 0.999))
+        torch.manual_seed(1000 + rank)         # same models on every rank (make_models seeds 0), its own ray batch on each
         rays = torch.randn(n, 2, 3, device=dev)
         rays[:, 0] = torch.tensor([0.0, 0.0, 4.0], device=dev)
         rays[:, 1, 2] = -1.0

@@ -211,6 +211,28 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
     static_assert(!(EPI == EPI_SIN || EPI == EPI_FILM) || KB >= 5, "sin rows are decoded one K block after their load");
     const auto mid = [&](auto kbc, auto sc) {
         constexpr int kb = decltype(kbc)::value, slot = decltype(sc)::value, j = kb * 8 + slot / 2;
+#if defined(MI_BWD_PHASES) && MI_BWD_PHASES
+        if constexpr (KB == 8) {
+            // EXPERIMENT (round 4): loads and stores in separate phases of the layer instead of interleaved in every K block
+            // (tools/probes/mfma_store_mix.hip: a row instruction costs 17 / 33 cycles among its own kind, 80-110 in a mix):
+            // the previous layer's dA rows go out in K blocks 0..2 (even slots 0..20: 11 per K block), the saved rows come in
+            // during K blocks 3..6 (slots 0, 3, .., 21: 8 per K block) and sin rows are decoded one K block later.
+            if constexpr (kb <= 2 && (slot & 1) == 0 && slot < 22) {
+                constexpr int js = kb * 11 + slot / 2;
+                if constexpr (js < PREV_MB * 4) {
+                    constexpr int m = js / 4, rg = js % 4;
+                    prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
+                }
+            }
+            if constexpr (kb >= 3 && slot % 3 == 0) {
+                constexpr int jl = (kb - 3) * 8 + slot / 3;
+                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 4 && jl - 8 >= 0 && jl - 8 < MB * 4) {
+                    sv[jl - 8] = dsin30_from_saved_x4(sv[jl - 8]);
+                }
+                if constexpr (EPI != EPI_LINEAR && kb <= 6 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+            }
+        } else
+#endif
         if constexpr (KB == 8) {
             // 8 K blocks: the row traffic is spread over the whole layer (tools/probes/mfma_store_mix.hip: 8 + 8 quarters
             // per K block run into a mixed read/write ceiling - 80-110 cycles per instruction instead of 17-33 - and

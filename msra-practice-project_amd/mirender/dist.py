@@ -112,14 +112,15 @@ def allreduce_grads(params, group=None, timing: list | None = None):
     flat = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat /= dist.get_world_size(group)
-    off = 0
+    views, off = [], 0
     for p in params:
-        g = flat[off:off + p.numel()].view_as(p)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        views.append(flat[off:off + p.numel()].view_as(p))
         off += p.numel()
+    for p, g in zip(params, views):
+        if p.grad is None:
+            p.grad = torch.empty_like(p)
+    # one multi-tensor copy instead of one small kernel per parameter (48 for two NeRFs: 0.1 ms of a 7 ms step otherwise)
+    torch._foreach_copy_([p.grad for p in params], views)
     if ev is not None:
         ev[1].record()
         timing.append(ev)
