@@ -379,3 +379,38 @@ def test_generic_path_without_grad_is_unchanged_and_detached():
     frozen_c, frozen_f = copy.deepcopy(cm).requires_grad_(False), copy.deepcopy(fm).requires_grad_(False)
     c = render_core.render_rays(rays, 2.0, 6.0, frozen_c, frozen_f, nc, nf, t_rand=tr)
     assert not any(x.requires_grad for x in c)
+
+
+@pytest.mark.parametrize("kind", ["nerf", "film_siren_nerf"])
+def test_points_mode_ranges_kept_or_recomputed_give_the_same_gradients(kind, monkeypatch):
+    """A fused module called on its own with more points than one backward range holds: the split into ranges (whole FiLM
+    groups per range), kept layer inputs and recomputed ones must all give the gradients of the single-range call."""
+    from mirender import autograd, fields
+    rng = np.random.Generator(np.random.PCG64(5))
+    M = 4 * 160
+    x = torch.from_numpy(np.concatenate([rng.uniform(-1, 1, size=(M, 3)), rng.normal(size=(M, 3))], -1).astype(np.float32)).to(dev())
+    c4 = torch.from_numpy(rng.normal(size=(M, 4)).astype(np.float32)).to(dev())
+    m = fields.field_from_state_dict(synth.state_dict(kind, seed=35, sharp="medium", bias_jitter=0.05), dev())
+    pf = fields.as_packed_field(m)
+    film = synth.film_params(4, seed=14).to(dev()).requires_grad_(True) if kind.startswith("film") else None
+    acts_bytes = 4 * autograd._lib.load().mi_field_train_acts_floats(pf.kind)
+    results = []
+    for per_range, keep in ((1 << 30, 1 << 40), (160, 1 << 40), (160, 0), (160, acts_bytes * 160 * 2)):
+        monkeypatch.setattr(autograd, "_max_points_per_chunk", lambda pf_, n=per_range: n)
+        monkeypatch.setattr(autograd, "SAVE_FINE_BYTES", keep)
+        for p in m.parameters():
+            p.grad = None
+        if film is not None:
+            film.grad = None
+        y = autograd.field_eval_points(pf, x, film)
+        assert y.requires_grad and tuple(y.shape) == (M, 4)
+        (y * c4).sum().backward()
+        results.append([y.detach().clone()] + [p.grad.clone() for p in m.parameters()] + ([] if film is None else [film.grad.clone()]))
+    for other in results[1:]:
+        assert torch.equal(results[0][0], other[0])                           # the forward values do not depend on the split
+        for a, b in zip(results[0][1:], other[1:]):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1e-3, float(a.abs().max()))
+    for a, b in zip(results[1][1:], results[2][1:]):                          # same ranges, kept vs recomputed: bit for bit
+        assert torch.equal(a, b)
+    for a, b in zip(results[1][1:], results[3][1:]):
+        assert torch.equal(a, b)

@@ -4,8 +4,8 @@
 rank; with mirender.dist.FORCE_COLLECTIVE they are issued anyway.  tests/rccl_one_rank.py - started here as a FRESH child
 process (it initialises its own `nccl` group; this process, which has already used the GPU, is never re-exec'ed) -
 renders a sharded frame, a data-parallel nerf step and a pi_GAN generator step through a one-rank RCCL group and
-compares each bit for bit with the ungrouped result.  Its output is kept as gpurun_out/r03_rccl_1rank.log (committed
-copy: profiles/r03_rccl_1rank.log)."""
+compares each bit for bit with the ungrouped result.  Its output is kept as gpurun_out/r04_rccl_1rank.log (committed
+copy: profiles/r04_rccl_1rank.log; round 3: profiles/r03_rccl_1rank.log)."""
 import os
 import subprocess
 import sys
@@ -31,7 +31,7 @@ def test_one_rank_rccl_group_runs_every_collective_of_the_product():
     log = f"$ NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL python tests/rccl_one_rank.py   (exit {r.returncode})\n" \
           f"--- stdout ---\n{r.stdout}\n--- stderr ---\n{r.stderr[-20000:]}\n"
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r03_rccl_1rank.log"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r04_rccl_1rank.log"), "w") as f:
         f.write(log)
     assert r.returncode == 0, log[-4000:]
     assert "backend nccl" in r.stdout and "rccl one-rank: OK" in r.stdout

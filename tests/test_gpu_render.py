@@ -9,7 +9,7 @@ oracle itself leaves 1e-4, no further from the fp64 evaluation than 1.5x the fp3
 pass re-samples depths through an ill-conditioned inverse CDF (the reference against itself in fp64
 moves 1-20 % of rays by > 1e-4), so the distance to the oracle's own end-to-end image is a distribution: the
 fraction of rays over 1e-4 may exceed the fp32 oracle's own fraction against fp64 by at most 0.02.  Achieved errors
-and the active bound of every check are written to gpurun_out/r03_parity.json (tests/conftest.py).
+and the active bound of every check are written to gpurun_out/r04_parity.json (tests/conftest.py).
 """
 import importlib.util
 import os
