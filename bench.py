@@ -181,7 +181,10 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         # GPUs), Nc=24 Nf=48, one whole training step = the D-step's generator forward (no grad, pi_GAN/train.py:108-111)
         # + the G-step forward/backward; the discriminator itself is stock PyTorch and not timed here.
         res, b, nc, nf = (256, 4, 24, 48) if c5 else (128, 32, 12, 24)
-        shrunk = os.environ.get("MI_BENCH_REHEARSAL") == "1" and world > 2
+        # MI_BENCH_REHEARSAL=1: all ranks share one device (gloo); =2: the same with the pi_GAN images always shrunk (the GPU test
+        # that runs the N = 2 command inside the suite, next to whatever the test process itself holds on the device)
+        rehearse = os.environ.get("MI_BENCH_REHEARSAL", "")
+        shrunk = (rehearse == "1" and world > 2) or rehearse == "2"
         if shrunk:                  # rehearsal with several ranks on ONE device: a full-size step per rank would not fit it
             res = 64
         torch.manual_seed(0)                   # the SAME generator on every rank (data-parallel replicas) ...
@@ -300,7 +303,7 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
         "config": {"workload": name, "rays_per_step_per_gpu": rays_per_step, "allocator_settle_steps": settle,
                    "warmup_requested": warmup, **extra,
                    "parallelism": (f"data-parallel x{world}, RCCL grad all-reduce" if world > 1 else "single GPU")
-                   + (" [REHEARSAL: all ranks on one device, gloo]" if os.environ.get("MI_BENCH_REHEARSAL") == "1" else "")},
+                   + (" [REHEARSAL: all ranks on one device, gloo]" if os.environ.get("MI_BENCH_REHEARSAL") in ("1", "2") else "")},
         "collective": {"backend": dist.get_backend() if dist.is_initialized() else None,
                        "n_ranks_seen": dist.get_world_size() if dist.is_initialized() else 1,
                        "grad_allreduce_bytes": int(sum(p.numel() for p in params if p.requires_grad) * 4),
@@ -427,7 +430,7 @@ def main():
     # Rehearsal switch for boxes with fewer GPUs than ranks (the build sessions have one): MI_BENCH_REHEARSAL=1 puts every
     # rank on device 0 and moves the collectives over gloo (RCCL refuses two ranks per device).  Never set by the driver;
     # the line says so in config.parallelism when it is.
-    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") == "1"
+    rehearsal = os.environ.get("MI_BENCH_REHEARSAL") in ("1", "2")
     if rehearsal:
         local = 0
     torch.cuda.set_device(local)

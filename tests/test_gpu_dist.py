@@ -92,3 +92,34 @@ def test_two_ranks_one_device_frame_and_training_step():
         for g, p in zip(grads, params):
             ref = p.grad.cpu().numpy()
             assert np.abs(g - ref).max() <= 2e-5 * max(1e-3, np.abs(ref).max())
+
+
+@pytest.mark.timeout(600)
+def test_the_drivers_two_gpu_command_end_to_end():
+    """`python bench.py --gpus 2 ...` exactly as the driver's scaling run starts it (the script spawns its own two ranks through
+    torch.distributed.run), with both ranks on this box's one device (MI_BENCH_REHEARSAL=2: gloo, the pi_GAN images shrunk so that
+    two steps fit next to whatever this test process holds): ONE JSON line comes back, the frame was ray-sharded over two ranks, and
+    its `train` object holds the nerf step and the C5 step with two ranks' step times and gradient all-reduce times."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.empty_cache()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MI_BENCH_REHEARSAL"] = "2"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-frame64"],
+                       env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["collective"]["n_ranks_seen"] == 2
+    assert len(d["collective"]["per_rank_allgather_ms"]) == 2 and d["value"] > 0
+    for wl in ("nerf_train", "c5"):
+        t = d["train"][wl]
+        assert t["n_ranks_seen"] == 2 and t["scaling"] == "weak" and t["ms_per_step"] > 0
+        assert len(t["per_rank_ms_per_step"]) == 2 and len(t["per_rank_grad_allreduce_ms"]) == 2
+        assert all(x is not None and x > 0 for x in t["per_rank_grad_allreduce_ms"])
+        assert t["grad_allreduce_bytes"] in (4751392, 7643152)
+        assert 0 < t["frac"] <= t["frac_reference_equivalent"] <= 1.0 + 1e-9
+    assert "c4" not in d["train"]                       # the batch-32 single-GPU configuration stays at N = 1
