@@ -51,6 +51,14 @@ def sources():
             stats[r["Name"]] = r
     fwd = next(v for k, v in stats.items() if "nerf_fwd_kernel<false, false>" in k)
     flops_fine = pmc["launch_points"][i] * 1182976
+    kinds = json.load(open(os.path.join(ROOT, f"profiles/{ROUND}_pmc_kinds.json")))["kernels"]
+    kb = lambda name: kinds[name]["mfma_busy_frac"]                                   # noqa: E731
+    pct = {}
+    with open(os.path.join(ROOT, f"profiles/{ROUND}_perf_kinds.log")) as f:
+        for ln in f:
+            m = re.match(r"(\w+)\s+fwd .*\(([\d.]+)% of fp32 MFMA peak\)", ln)
+            if m:
+                pct[m.group(1)] = float(m.group(2))
     fam = bench["psnr_vs_ref"]["families"]
     tr = bench["train"]
     return dict(
@@ -60,7 +68,7 @@ def sources():
         bpp=d["hbm_bytes_per_point_upper"], gbps=d["hbm_GBps_upper"], lds=d["lds_bank_conflict_cycles"],
         insts_mfma=pmc["counters"]["SQ_INSTS_MFMA"][i], mfma_per_wave=pmc["counters"]["SQ_INSTS_MFMA"][i] / waves,
         flops_issued=d["mfma_flops_issued"], flops_alg=flops_fine,
-        stats_calls=int(fwd["Calls"]), stats_avg_ms=float(fwd["AverageNs"]) / 1e6, fam=fam, tr=tr)
+        stats_calls=int(fwd["Calls"]), stats_avg_ms=float(fwd["AverageNs"]) / 1e6, fam=fam, tr=tr, kb=kb, pct=pct)
 
 
 def checks(s):
@@ -80,6 +88,13 @@ def checks(s):
         (r"`nerf_fwd_kernel<false,false>` (\d+) launches, average ([\d.]+) ms \(coarse \+ fine launch of a step = ([\d .]+) ms\)",
          [s["stats_calls"], s["stats_avg_ms"], 2 * s["stats_avg_ms"]]),
         (r"besides its ([\d ]+) MFMAs \(", [s["mfma_per_wave"]]),
+        (r"`profiles/r04_perf_kinds.log`\): NeRF ([\d.]+) %, TinyNeRF ([\d.]+) %, SirenNeRF ([\d.]+) %, FilmSirenNeRF ([\d.]+) % of",
+         [s["pct"]["nerf"], s["pct"]["tiny"], s["pct"]["siren"], s["pct"]["film"]]),
+        (r"`profiles/r04_pmc_kinds.json`\): ([\d.]+) / ([\d.]+) / ([\d.]+) / ([\d.]+), and - a NeRF training step at 8 192 rays - saving forward ([\d.]+), chain ([\d.]+),\s+256x256 dW GEMMs ([\d.]+), the narrow tiles ([\d.]+) \(128x256\) / ([\d.]+) \(256x64\) / ([\d.]+) \(128x32\)",
+         [s["kb"]("mi::nerf_fwd_kernel<false, false>"), s["kb"]("mi::nerf_fwd_kernel<true, false>"), s["kb"]("mi::siren_fwd_kernel<false>"),
+          s["kb"]("mi::film_fwd_kernel<true, false>"), s["kb"]("mi::nerf_fwd_kernel<false, true>"), s["kb"]("mi::nerf_bwd_kernel<false>"),
+          s["kb"]("mi::dw_gemm_kernel<4, 2, 2>"), s["kb"]("mi::dw_gemm_kernel<4, 1, 2>"), s["kb"]("mi::dw_gemm_kernel<2, 2, 1>"),
+          s["kb"]("mi::dw_gemm_kernel<1, 1, 1>")]),
         # section 6: the bench line
         (r"one MI355X\): ([\d ]+) rays/s, ([\d .]+) ms per frame, `roofline.frac` ([\d.]+)\s+\(([\d.]+) TFLOP/s; average MLP launch ([\d.]+) ms",
          [b["value"], b["ms_per_step"], r["frac"], r["achieved"], r["avg_launch_ms"]]),
