@@ -191,3 +191,37 @@ def test_w0_is_the_modules_own_whichever_path_renders_it(monkeypatch):
     with torch.no_grad():
         ref30 = R.render_rays(rays, 0.5, 1.5, fo30, fo30, 8, 16, tr)
     assert float((ref30.rgb_c - ref25.rgb_c).abs().max()) > 1e-2
+
+
+@pytest.mark.parametrize("w_0", [1.0, 7.5, 30.0, 60.0, 120.0])
+def test_fused_film_field_follows_w0_over_two_decades(w_0):
+    """The FiLM kernels read w_0 from the packed stream (pi_GAN/modules.py:11,73): free-standing points through
+    `fields.FilmSirenNeRF(w_0=w)` against the oracle evaluated with that w_0, weights as the reference initialises them FOR
+    that w_0 (modules.py:27-31 divides the hidden layers' range by w_0).  A larger w_0 amplifies every fp32 pipeline's rounding
+    (t = fl(w_0 u) grows), so the gate is the one the x50 heads use: no further from the fp64 evaluation than 2x the fp32
+    oracle's own distance, or the flat 1e-4 where that holds."""
+    from mirender import fields
+    from oracle import fields as ofields, parity
+    torch.manual_seed(int(w_0 * 10))
+    m = fields.FilmSirenNeRF(w_0=w_0).to(dev())
+    assert fields.as_packed_field(m).w_0 == w_0
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    rng = np.random.Generator(np.random.PCG64(3))
+    M = 2048
+    x = torch.from_numpy(np.concatenate([rng.uniform(-1, 1, size=(M, 3)), rng.normal(size=(M, 3))], -1).astype(np.float32))
+    x[:, 3:] /= x[:, 3:].norm(dim=-1, keepdim=True)
+    film = synth.film_params(1, seed=21)
+    m.set_film_params(film[0].to(dev()))
+    with torch.no_grad():
+        got = m(x.to(dev())).cpu()
+    old = ofields.W0
+    try:
+        ofields.W0 = w_0
+        ref32 = ofields.make_field("film_siren_nerf", sd, film[0])(x)
+        ref64 = ofields.make_field("film_siren_nerf", {k: v.double() for k, v in sd.items()}, film[0].double())(x.double())
+    finally:
+        ofields.W0 = old
+    case = f"fused FilmSirenNeRF(w_0={w_0:g}), {M} free-standing points, reference initialisation for that w_0"
+    parity.gate(case, "field", "rgb", got[:, :3], ref32[:, :3], ref64[:, :3], factor=parity.FP64_FACTOR_INTERMEDIATE)
+    parity.gate(case, "field", "sigma", got[:, 3], ref32[:, 3], ref64[:, 3], factor=parity.FP64_FACTOR_INTERMEDIATE)
+    assert float(got[:, :3].std()) > 1e-3                                  # the field is not constant: w_0 really acts
