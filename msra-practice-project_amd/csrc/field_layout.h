@@ -220,11 +220,16 @@ constexpr int region_total(const RegionLayout& L) { return region_offset(L, L.n)
 
 // NeRF acts: 0 E_pos(64) | 1..8 H1..H8 (post-ReLU outputs of layers_pos.0..7) | 9 G (layers_dir.0 out) |
 //            10 E_dir(32) | 11 H_d (post-ReLU layers_dir.1, 128)
-constexpr RegionLayout nerf_acts() { return {12, {64, 256, 256, 256, 256, 256, 256, 256, 256, 256, 32, 128}}; }
+//            12..19 ReLU switches of H1..H8 (8 dwords = 256 bits per point) | 20 of H_d (4 dwords): what the backward CHAIN
+//            needs of a ReLU layer is one bit per unit (the dW GEMMs read the rows themselves); lane (point, half h) owns
+//            dwords [4h, 4h + 4) (H_d: [2h, 2h + 2)), the bit of block m, quarter rg, element q = 31 - (16 (m & 1) + 4 rg + q)
+//            of dword m >> 1 (relu_switch_in / relu_switch_of in field_mlp_device.h)
+constexpr RegionLayout nerf_acts() { return {21, {64, 256, 256, 256, 256, 256, 256, 256, 256, 256, 32, 128, 8, 8, 8, 8, 8, 8, 8, 8, 4}}; }
 // NeRF grads: 0..7 dA of layers_pos.0..7 | 8 dA layers_dir.0 | 9 dA layers_dir.1 (128) | 10 head pre-act grads (4)
 constexpr RegionLayout nerf_grads() { return {11, {256, 256, 256, 256, 256, 256, 256, 256, 256, 128, 4}}; }
 // TinyNeRF acts: 0 E_pos | 1..4 H1..H4 | 5 E_dir(32) | 6 H_d(128); grads: 0..3 | 4 dA dir (128) | 5 heads (4)
-constexpr RegionLayout tiny_acts() { return {7, {64, 256, 256, 256, 256, 32, 128}}; }
+//                7..10 ReLU switches of H1..H4 (8 dwords per point) | 11 of H_d (4 dwords), as in nerf_acts()
+constexpr RegionLayout tiny_acts() { return {12, {64, 256, 256, 256, 256, 32, 128, 8, 8, 8, 8, 4}}; }
 constexpr RegionLayout tiny_grads() { return {6, {256, 256, 256, 256, 128, 4}}; }
 
 // SirenNeRF acts: 0 xin(8: xyz, dir, 0, 0) | l = 1..8: X_l = sin(30 A_{l-1}) with the sign of cos(30 A_{l-1}) in its

@@ -118,9 +118,12 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
 
     constexpr RegionLayout RL = TINY ? tiny_acts() : nerf_acts();
     const int64_t SP = a.save_points;
-    const auto rows = [&](int off_floats_per_point, int width) {
-        return SaveRows{SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, width, pt.p, pt.valid};
+    // `sw`: the region of the layer's ReLU switch bits (nerf_acts() 12.. / tiny_acts() 7..), -1 for none
+    const auto rows = [&](int off_floats_per_point, int width, int sw = -1) {
+        return SaveRows{SAVE ? a.save + (int64_t)off_floats_per_point * SP : nullptr, width, pt.p, pt.valid,
+                        SAVE && sw >= 0 ? a.save + (int64_t)region_offset(RL, sw) * SP : nullptr};
     };
+    constexpr int SW0 = TINY ? 7 : 12;                     // switch region of H1; H_l: SW0 + l - 1; H_d: the last region
     if constexpr (SAVE) {
         f32x16 tmp[8];
         tmp[0] = pe[0]; tmp[1] = pe[1];
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     int slot = 0;
     MI_STAMP(a, 1);
     // layers_pos[0]: 60 -> 256
-    fwd_layer<2, 8, false, 1, 32, false, ACT_RELU, SAVE, true>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc, X, nullptr, rows(64, 256));
+    fwd_layer<2, 8, false, 1, 32, false, ACT_RELU, SAVE, true>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_pe, acc, X, nullptr, rows(64, 256, SW0));
     slot ^= 1;                                                          // H1
     MI_STAMP(a, 3);
     float sigma;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
             if (l == 2 && a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;   // rows of layers_pos[2]: 32..64
 #endif
             fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                          rows(64 + 256 * l, 256), rows(64 + 256 * (l - 1), 256));   // H2..H5
+                                                                          rows(64 + 256 * l, 256, SW0 + l), rows(64 + 256 * (l - 1), 256));   // H2..H5
             slot ^= 1;
             MI_ROW_STAMP(c);
 #ifdef MI_PROFILE_STAMPS
@@ -165,17 +168,17 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
         }
         // layers_pos[5]: [PE(60) | h(256)] -> 256
         fwd_layer<10, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_skip, acc, X, nullptr,
-                                                                       rows(region_offset(RL, 6), 256), rows(region_offset(RL, 5), 256));   // H6
+                                                                       rows(region_offset(RL, 6), 256, SW0 + 5), rows(region_offset(RL, 5), 256));   // H6
         slot ^= 1;
         MI_STAMP(a, 13);
         // layers_pos[6]
         fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                      rows(region_offset(RL, 7), 256), rows(region_offset(RL, 6), 256));    // H7
+                                                                      rows(region_offset(RL, 7), 256, SW0 + 6), rows(region_offset(RL, 6), 256));    // H7
         slot ^= 1;
         MI_STAMP(a, 15);
         // layers_pos[7] (+ sigma head pieces)
         fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                      rows(region_offset(RL, 8), 256), rows(region_offset(RL, 7), 256));    // H8
+                                                                      rows(region_offset(RL, 8), 256, SW0 + 7), rows(region_offset(RL, 7), 256));    // H8
         {
             const float* aux = smem + kLdsAux0 + slot * kLdsAux;
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
@@ -190,13 +193,13 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     } else {
         // layers_pos[1], [2], [3] (+ sigma head pieces), then the dir layer's 5 aux pieces
         fwd_layer<8, 8, false, 1, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                      rows(region_offset(RL, 2), 256), rows(region_offset(RL, 1), 256));
+                                                                      rows(region_offset(RL, 2), 256, SW0 + 1), rows(region_offset(RL, 1), 256));
         slot ^= 1;
         fwd_layer<8, 8, false, 3, 32, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                      rows(region_offset(RL, 3), 256), rows(region_offset(RL, 2), 256));
+                                                                      rows(region_offset(RL, 3), 256, SW0 + 2), rows(region_offset(RL, 2), 256));
         slot ^= 1;
         fwd_layer<8, 8, false, 5, 16, false, ACT_RELU, SAVE, true, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_x, acc, X, nullptr,
-                                                                      rows(region_offset(RL, 4), 256), rows(region_offset(RL, 3), 256));
+                                                                      rows(region_offset(RL, 4), 256, SW0 + 3), rows(region_offset(RL, 3), 256));
         {
             const float* aux = smem + kLdsAux0 + slot * kLdsAux;
             sigma = fmaxf(head_dot<8>(X, aux, 1, c.h) + aux[2 * kPiece], 0.f);
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void nerf_fwd_kernel(MlpArgs a) {
     }
     // layers_dir[1] (TinyNeRF: layers_dir[0]): [h(256) | PE_dir(24)] -> 128, relu; then rgb head
     fwd_layer<9, 4, false, 0, 0, false, ACT_RELU, SAVE, false, 8>(c, slot, 0, 0, 0.f, 0.f, 0.f, sel_dir, acc, X, nullptr,
-                                                                  rows(region_offset(RL, TINY ? 6 : 11), 128),
+                                                                  rows(region_offset(RL, TINY ? 6 : 11), 128, RL.n - 1),
                                                                   rows(region_offset(RL, TINY ? 4 : 9), 256));   // H_d; G / H4 from X
     MI_STAMP(a, 20);
     const float* aux = smem + kLdsAux0 + slot * kLdsAux;

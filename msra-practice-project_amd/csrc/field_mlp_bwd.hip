@@ -127,25 +127,32 @@ __device__ __forceinline__ void load_saved_row(f32x4 (&sv)[MB * 4], const float*
     for (int j = 0; j < MB * 4; ++j) sv[j] = row[(j / 4) * 8 + (j % 4) * 2];
 }
 
-// dA = dX (.) relu'(H) with H the saved post-ReLU activation (`hsv`, loaded by load_saved_row); stores dA rows and leaves
-// them in X.
+// A lane's switch words of a ReLU layer (field_layout.h nerf_acts() 12..: MB / 2 dwords per (point, half)), one load
 template <int MB>
-__device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const f32x4 (&hsv)[MB * 4],
+__device__ __forceinline__ void load_switches(uint32_t (&mw)[4], const float* __restrict__ sw, int64_t p, int h) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(sw) + (p * 2 + h) * (MB / 2);
+    if constexpr (MB == 8) { const uint4 v = *reinterpret_cast<const uint4*>(src); mw[0] = v.x; mw[1] = v.y; mw[2] = v.z; mw[3] = v.w; }
+    else { const uint2 v = *reinterpret_cast<const uint2*>(src); mw[0] = v.x; mw[1] = v.y; mw[2] = 0u; mw[3] = 0u; }
+}
+
+// dA = dX (.) relu'(H): the layer's switch bits (`mw`, load_switches) ANDed onto dX; stores dA rows and leaves them in X.
+template <int MB>
+__device__ __forceinline__ void relu_bwd_store(const f32x16 (&dX)[8], f32x16 (&X)[8], const uint32_t (&mw)[4],
                                                float* __restrict__ dA, int64_t ld, int64_t p, bool valid, int h) {
     f32x4* drow = reinterpret_cast<f32x4*>(dA + p * ld + 4 * h);
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 hv = hsv[m * 4 + rg];
+    static_for<MB>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        static_for<4>([&](auto rc) {
+            constexpr int rg = decltype(rc)::value;
             f32x4 o;
-            o.x = hv.x > 0.f ? dX[m][4 * rg + 0] : 0.f;
-            o.y = hv.y > 0.f ? dX[m][4 * rg + 1] : 0.f;
-            o.z = hv.z > 0.f ? dX[m][4 * rg + 2] : 0.f;
-            o.w = hv.w > 0.f ? dX[m][4 * rg + 3] : 0.f;
+            o.x = __uint_as_float(__float_as_uint(dX[m][4 * rg + 0]) & relu_switch_of<m, rg, 0>(mw));
+            o.y = __uint_as_float(__float_as_uint(dX[m][4 * rg + 1]) & relu_switch_of<m, rg, 1>(mw));
+            o.z = __uint_as_float(__float_as_uint(dX[m][4 * rg + 2]) & relu_switch_of<m, rg, 2>(mw));
+            o.w = __uint_as_float(__float_as_uint(dX[m][4 * rg + 3]) & relu_switch_of<m, rg, 3>(mw));
             X[m][4 * rg + 0] = o.x; X[m][4 * rg + 1] = o.y; X[m][4 * rg + 2] = o.z; X[m][4 * rg + 3] = o.w;
             drow[m * 8 + rg * 2] = o;
-        }
+        });
+    });
 }
 
 
@@ -200,7 +207,10 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
     const RowRef<const f32x4> srow{reinterpret_cast<const char*>(saved + tile0 * ld), (lrow * (uint32_t)ld + 4u * h) * 4u};
     const RowRef<f32x4> drow{reinterpret_cast<char*>(dA + tile0 * ld), (lrow * (uint32_t)ld + 4u * h) * 4u};
     const RowRef<f32x4> prow{reinterpret_cast<char*>(prev_dA + tile0 * prev_ld), (lrow * (uint32_t)prev_ld + 4u * h) * 4u};
-    f32x4 sv[EPI == EPI_LINEAR ? 1 : MB * 4];
+    // ReLU layers: `saved` is the layer's SWITCH region (one bit per unit, MB / 2 dwords per lane: one load in the layer's
+    // first mid slot) - round 4; sin layers: the saved X rows, a quarter per slot, decoded one K block later
+    f32x4 sv[(EPI == EPI_LINEAR || EPI == EPI_RELU) ? 1 : MB * 4];
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};
     const auto pre = [&](auto mc, auto pc) {
         constexpr int m = decltype(mc)::value, rg = decltype(pc)::value;
         if constexpr (SCALED) {
@@ -229,7 +239,8 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
                 if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 4 && jl - 8 >= 0 && jl - 8 < MB * 4) {
                     sv[jl - 8] = dsin30_from_saved_x4(sv[jl - 8]);
                 }
-                if constexpr (EPI != EPI_LINEAR && kb <= 6 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb <= 6 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+                if constexpr (EPI == EPI_RELU && kb == 3 && slot == 0) load_switches<MB>(mw, saved, p, h);
             }
         } else
 #endif
@@ -246,7 +257,8 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
                 if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 2 && jl - 6 >= 0 && jl - 6 < MB * 4) {
                     sv[jl - 6] = dsin30_from_saved_x4(sv[jl - 6]);
                 }
-                if constexpr (EPI != EPI_LINEAR && kb >= 1 && kb < 7 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && kb >= 1 && kb < 7 && jl < MB * 4) sv[jl] = srow[(jl / 4) * 8 + (jl % 4) * 2];
+                if constexpr (EPI == EPI_RELU && kb == 1 && slot == 0) load_switches<MB>(mw, saved, p, h);
             } else if constexpr ((slot & 3) == 2 && slot < 16) {
                 constexpr int js = kb * 4 + slot / 4;
                 if constexpr (js < PREV_MB * 4) {
@@ -260,7 +272,8 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
         }
         if constexpr (KB != 8 && kb < 4 && slot < 16) {          // 4 K blocks: all 16 mid slots of rows 1-2 are needed
             if constexpr ((slot & 1) == 0) {
-                if constexpr (EPI != EPI_LINEAR && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
+                if constexpr ((EPI == EPI_SIN || EPI == EPI_FILM) && j < MB * 4) sv[j] = srow[(j / 4) * 8 + (j % 4) * 2];
+                if constexpr (EPI == EPI_RELU && j == 0) load_switches<MB>(mw, saved, p, h);
             } else if constexpr (j < PREV_MB * 4) {
                 constexpr int m = j / 4, rg = j % 4;
                 prow[m * 8 + rg * 2] = f32x4{X[m][4 * rg + 0], X[m][4 * rg + 1], X[m][4 * rg + 2], X[m][4 * rg + 3]};
@@ -274,8 +287,11 @@ __device__ __forceinline__ void bwd_layer(Ctx& c, int aux_slot, int piece, float
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float d = acc[m][4 * rg + q];
-            if constexpr (EPI == EPI_RELU) o[q] = sv[m * 4 + rg][q] > 0.f ? d : 0.f;
-            else if constexpr (EPI == EPI_SIN || EPI == EPI_FILM) o[q] = sv[m * 4 + rg][q] * d;
+            if constexpr (EPI == EPI_RELU) {
+                const uint32_t on = q == 0 ? relu_switch_of<m, rg, 0>(mw) : q == 1 ? relu_switch_of<m, rg, 1>(mw)
+                                  : q == 2 ? relu_switch_of<m, rg, 2>(mw) : relu_switch_of<m, rg, 3>(mw);
+                o[q] = __uint_as_float(__float_as_uint(d) & on);
+            } else if constexpr (EPI == EPI_SIN || EPI == EPI_FILM) o[q] = sv[m * 4 + rg][q] * d;
             else o[q] = d;
             if constexpr (EPI == EPI_FILM) X[m][4 * rg + q] = o[q] * g[q];
             else X[m][4 * rg + q] = o[q];
@@ -317,8 +333,11 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
     const auto sel_x = [&](auto kb) -> const f32x16& { return X[decltype(kb)::value]; };
     const auto acts = [&](int region) { return a.acts + (int64_t)region_offset(AL, region) * P; };
     const auto grads = [&](int region) { return a.grads + (int64_t)region_offset(GL, region) * P; };
-    f32x4 hsv[16];
-    load_saved_row<4>(hsv, acts(TINY ? 6 : 11), 128, p, c.h);
+    // ReLU switches (one bit per unit) of layer H_l: region SW0 + l - 1, of the dir layer H_d: the last region
+    constexpr int SW0 = TINY ? 7 : 12;
+    const auto sw = [&](int l) { return a.acts + ((int64_t)region_offset(AL, SW0) + 8 * (l - 1)) * P; };
+    uint32_t hsw[4];
+    load_switches<4>(hsw, acts(AL.n - 1), p, c.h);
     MI_STAMP(a, 0);
 
     __syncthreads();                                        // head rows (and K block 0) have landed
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
                 acc[m][4 * rg + 3] = fmaf(w2.w, d2, fmaf(w1.w, d1, w0.w * d0));
             }
     }
-    relu_bwd_store<4>(acc, X, hsv, grads(TINY ? 4 : 9), 128, p, valid, c.h);                    // dA of the dir layer
+    relu_bwd_store<4>(acc, X, hsw, grads(TINY ? 4 : 9), 128, p, valid, c.h);                    // dA of the dir layer
     MI_STAMP(a, 1);
 
     int slot = 0;
@@ -350,29 +369,29 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
         MI_STAMP(a, 2);
         slot ^= 1;
         // layers_dir[0]^T, plus the sigma head's contribution to dH8; dA7 = dH8 (.) [H8>0]
-        bwd_layer<8, 8, 0, 32, EPI_RELU, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, acts(8), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
+        bwd_layer<8, 8, 0, 32, EPI_RELU, true, false, true, 8>(c, slot, 0, ds, sel_x, acc, X, sw(8), grads(7), 256, p, valid, -1, 0, nullptr, grads(8), 256);
         MI_STAMP(a, 3);
         slot ^= 1;
 #ifdef MI_PROFILE_STAMPS
         if (a.stamps) c.rowst = a.stamps + (int64_t)blockIdx.x * 128 + 32;                     // rows of L7^T: 32..64
 #endif
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(7), grads(6), 256, p, valid, -1, 0, nullptr, grads(7), 256);  // L7^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(7), grads(6), 256, p, valid, -1, 0, nullptr, grads(7), 256);  // L7^T
 #ifdef MI_PROFILE_STAMPS
         if (c.rowst) { MI_ROW_STAMP(c); }
         c.rowst = nullptr;
 #endif
         MI_STAMP(a, 4);
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(6), grads(5), 256, p, valid, -1, 0, nullptr, grads(6), 256);  // L6^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(6), grads(5), 256, p, valid, -1, 0, nullptr, grads(6), 256);  // L6^T
         MI_STAMP(a, 5);
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(5), grads(4), 256, p, valid, -1, 0, nullptr, grads(5), 256);  // L5^T (h part)
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(5), grads(4), 256, p, valid, -1, 0, nullptr, grads(5), 256);  // L5^T (h part)
         MI_STAMP(a, 6);
 #pragma unroll 1
         for (int l = 4; l >= 2; --l)                                                           // L4^T .. L2^T
-            bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, a.acts + (int64_t)(64 + 256 * (l - 1)) * P,
+            bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(l),
                                                                     a.grads + (int64_t)(256 * (l - 1)) * P, 256, p, valid, -1, 0, nullptr,
                                                                     a.grads + (int64_t)(256 * l) * P, 256);
         MI_STAMP(a, 7);                                                                        // after L4^T .. L2^T
-        bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
+        bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
         MI_STAMP(a, 8);
     } else {
         // dir layer^T with the sigma head's contribution to dH4 (sigma row is aux piece 3 of slot 0)
@@ -380,10 +399,10 @@ __global__ __launch_bounds__(256, 1) void nerf_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) Bd[m] = X[m];
         const auto sel_d = [&](auto kb) -> const f32x16& { return Bd[decltype(kb)::value]; };
-        bwd_layer<4, 8, 0, 32, EPI_RELU, true, false, true, 0>(c, 0, 3, ds, sel_d, acc, X, acts(4), grads(3), 256, p, valid);
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(3), grads(2), 256, p, valid, -1, 0, nullptr, grads(3), 256);  // L3^T
-        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(2), grads(1), 256, p, valid, -1, 0, nullptr, grads(2), 256);  // L2^T
-        bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, acts(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
+        bwd_layer<4, 8, 0, 32, EPI_RELU, true, false, true, 0>(c, 0, 3, ds, sel_d, acc, X, sw(4), grads(3), 256, p, valid);
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(3), grads(2), 256, p, valid, -1, 0, nullptr, grads(3), 256);  // L3^T
+        bwd_layer<8, 8, 0, 32, EPI_RELU, false, false, true, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(2), grads(1), 256, p, valid, -1, 0, nullptr, grads(2), 256);  // L2^T
+        bwd_layer<8, 8, 0, 0, EPI_RELU, false, false, false, 8>(c, slot, 0, 0.f, sel_x, acc, X, sw(1), grads(0), 256, p, valid, -1, 0, nullptr, grads(1), 256);   // L1^T
     }
 }
 

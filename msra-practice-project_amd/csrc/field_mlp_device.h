@@ -378,7 +378,21 @@ struct SaveRows {
     float* x;
     int64_t ld, p;
     bool valid;
+    float* mask = nullptr;      // ReLU layers: the region of the layer's switch bits (field_layout.h nerf_acts()), or null
 };
+
+// A ReLU layer's switches for the backward chain, one bit per unit, shifted into a lane's words as the epilogue produces the
+// units (posts run in ascending (block m, quarter rg) order in every mma_chunk ordering, elements q = 0..3 inside a post):
+// word m >> 1 receives 32 bits, unit (m, rg, q) ends at bit 31 - (16 (m & 1) + 4 rg + q).  v_cmp + v_addc: two VALU
+// instructions per unit, exactly torch's relu' = [output > 0].
+__device__ __forceinline__ void relu_switch_in(uint32_t& w, float o) {
+    asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(w) : "v"(o) : "vcc");
+}
+// ... and read back: 0xffffffff if the unit was on, else 0 (v_bfe_i32), to be ANDed onto the incoming gradient
+template <int M, int RG, int Q>
+__device__ __forceinline__ uint32_t relu_switch_of(const uint32_t (&w)[4]) {
+    return (uint32_t)__builtin_amdgcn_sbfe(w[M >> 1], 31 - (16 * (M & 1) + 4 * RG + Q), 1);
+}
 
 // One forward layer with its accumulator start (K = 3 products, else none: srcC = 0) and its epilogue (bias,
 // activation, training stores) sliced between the MFMAs of its first / last K block.  X <- act(W . [inputs] + b); the
@@ -400,6 +414,7 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
     lds4_t pf = nullptr;
     if constexpr (ACT == ACT_FILM) pf = lds_base(film_row + h * 4);
     f32x4 bias_q[2], g_q[2], bb_q[2];
+    uint32_t mw[4] = {0u, 0u, 0u, 0u};           // ReLU + SAVE: the layer's switch bits (relu_switch_in)
     constexpr bool kSinAct = ACT == ACT_SIN30 || ACT == ACT_FILM;
     // epilogues that store their own rows (training forward of a sin layer: the saved rows are an ENCODING of X that the
     // registers do not carry on, so they cannot be deferred to the next layer's slots) are spread over the whole last K
@@ -443,7 +458,14 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
         // dependent packed op waits a state on its predecessor (mi_math.h:hw_turns30_x4)
         f32x4 v = f32x4{acc[m][4 * rg + 0], acc[m][4 * rg + 1], acc[m][4 * rg + 2], acc[m][4 * rg + 3]} + bias;
         f32x4 o, xo;
-        if constexpr (ACT == ACT_RELU) { o = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}; xo = o; }
+        if constexpr (ACT == ACT_RELU) {
+            o = f32x4{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)};
+            xo = o;
+            if constexpr (SAVE) {
+                relu_switch_in(mw[m >> 1], o.x); relu_switch_in(mw[m >> 1], o.y);
+                relu_switch_in(mw[m >> 1], o.z); relu_switch_in(mw[m >> 1], o.w);
+            }
+        }
         else if constexpr (ACT == ACT_LINEAR) { o = v; xo = o; }
         else {
             if constexpr (ACT == ACT_FILM) v = film_affine(g_q[idx & 1], v, bb_q[idx & 1]);
@@ -487,6 +509,14 @@ __device__ __forceinline__ void fwd_layer(Ctx& c, int aux_slot, int next_film_la
         mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3, kSpread>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post, mid);
     } else {
         mma_layer_fn<KB, MB, 0, NEXT_AUX, NEXT_BLOCK, FILM, true, !K3, kSpread>(c, aux_slot, next_film_layer, NoHook{}, bsel, acc, pre, post);
+    }
+    if constexpr (ACT == ACT_RELU && SAVE) {
+        // one 16-byte (MB = 8) or 8-byte (MB = 4) store per lane: the wave's 32 points x 2 halves are contiguous
+        if (sv.mask) {
+            uint32_t* dst = reinterpret_cast<uint32_t*>(sv.mask) + (sv.p * 2 + h) * (MB / 2);
+            if constexpr (MB == 8) *reinterpret_cast<uint4*>(dst) = uint4{mw[0], mw[1], mw[2], mw[3]};
+            else { static_assert(MB == 4, "ReLU layers are 256 or 128 wide"); *reinterpret_cast<uint2*>(dst) = uint2{mw[0], mw[1]}; }
+        }
     }
 }
 
