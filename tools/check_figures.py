@@ -124,6 +124,50 @@ def checks(s):
     return [("DESIGN.md", design), ("README.md", readme)]
 
 
+def _format_like(text: str, value: float) -> str:
+    """`value` printed the way `text` prints its number: same decimals, thin-space thousands, mantissa digits of an e-notation."""
+    t = text.strip()
+    if "e" in t.lower():
+        mant, _, exp = t.lower().partition("e")
+        frac = len(mant.split(".")[1]) if "." in mant else 0
+        e = int(exp)
+        out = f"{value / 10.0 ** e:.{frac}f}e{exp}"
+        return out
+    frac = len(t.split(".")[1]) if "." in t else 0
+    out = f"{value:.{frac}f}"
+    if " " in t or "\u2009" in t:                       # grouped thousands ("482 252")
+        whole, dot, rest = out.partition(".")
+        groups = []
+        while len(whole) > 3:
+            groups.insert(0, whole[-3:])
+            whole = whole[:-3]
+        out = " ".join([whole] + groups) + dot + rest
+    return out
+
+
+def fix():
+    """Rewrite every checked number in DESIGN.md / README.md from the tracked files, keeping each number's printed format
+    (after a new profiling round: `python tools/summarise_pmc.py rNN && python tools/check_figures.py --fix`)."""
+    s = sources()
+    for doc, items in checks(s):
+        path = os.path.join(ROOT, doc)
+        text = open(path).read()
+        for pattern, want in items:
+            m = re.search(pattern, text)
+            if not m:
+                print(f"{doc}: sentence not found: /{pattern[:90]}.../")
+                continue
+            piece = m.group(0)
+            new, last = "", 0
+            for gi, w in enumerate(want, start=1):
+                a, b = m.start(gi) - m.start(0), m.end(gi) - m.start(0)
+                new += piece[last:a] + _format_like(m.group(gi), w)
+                last = b
+            new += piece[last:]
+            text = text[:m.start(0)] + new + text[m.end(0):]
+        open(path, "w").write(text)
+
+
 def main(verbose=True, slack=2e-4):
     s = sources()
     failures = []
@@ -146,7 +190,9 @@ def main(verbose=True, slack=2e-4):
 
 
 if __name__ == "__main__":
-    bad = main()
+    if "--fix" in sys.argv:
+        fix()
+    bad = main(verbose="--fix" not in sys.argv)
     for f in bad:
         print("MISMATCH:", f)
     sys.exit(1 if bad else 0)
