@@ -277,7 +277,7 @@ def train_workload(args, world, rank, dev, workload=None, steps=None, warmup=Non
     # comparable to the MFMA-busy counters.  SURVEY.md 8d's count of what the REFERENCE executes (it evaluates the Nc coarse
     # points a second time in the fine pass) is carried next to it under an explicit name.
     achieved_ref = flops * steps / elapsed / 1e12                         # per GPU: every rank runs its own `flops` per step
-    achieved = achieved_ref * evals_executed / evals
+    achieved = achieved_ref if evals_executed == evals else achieved_ref * evals_executed / evals
     # HBM bytes per step: not measurable from inside the process; from the committed rocprofv3 PMC passes of this same
     # workload (profiles/rNN_pmc_<workload>.json: WRITE_SIZE + 2 x FETCH_SIZE summed over every kernel of the traced run,
     # tools/summarise_pmc.py) divided by the number of steps that run traced - its --steps 1 --warmup 1 plus, for the

@@ -121,5 +121,5 @@ def test_the_drivers_two_gpu_command_end_to_end():
         assert len(t["per_rank_ms_per_step"]) == 2 and len(t["per_rank_grad_allreduce_ms"]) == 2
         assert all(x is not None and x > 0 for x in t["per_rank_grad_allreduce_ms"])
         assert t["grad_allreduce_bytes"] in (4751392, 7643152)
-        assert 0 < t["frac"] <= t["frac_reference_equivalent"] <= 1.0 + 1e-9
+        assert 0 < t["frac"] <= t["frac_reference_equivalent"] * (1 + 1e-12) <= 1.0 + 1e-9
     assert "c4" not in d["train"]                       # the batch-32 single-GPU configuration stays at N = 1
